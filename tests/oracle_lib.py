@@ -1,0 +1,211 @@
+"""ctypes binding of the CPU oracle (oracle/_build/libwgsl_oracle.so).
+
+Test infrastructure: imported by tests/, bench.py's cpu_baseline leg and
+__graft_entry__.smoke() only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ORACLE_DIR = os.path.join(_ROOT, "oracle")
+_SO = os.path.join(_ORACLE_DIR, "_build", "libwgsl_oracle.so")
+
+
+class OrcHit(C.Structure):
+    _fields_ = [
+        ("t", C.c_float),
+        ("color", C.c_float * 3),
+        ("normal", C.c_float * 3),
+        ("emission", C.c_float * 3),
+        ("smoothness", C.c_float),
+        ("specularProbability", C.c_float),
+        ("id", C.c_int32),
+    ]
+
+
+def build() -> str:
+    """Compile the oracle if the library is missing or older than its sources."""
+    srcs = [os.path.join(_ORACLE_DIR, f) for f in ("wgsl_oracle.c", "wgsl_oracle.h", "Makefile")]
+    if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = C.CDLL(build())
+    fp = C.POINTER(C.c_float)
+    L.orc_wang_hash.argtypes = [C.c_uint32]
+    L.orc_wang_hash.restype = C.c_uint32
+    L.orc_rand_f.argtypes = [C.POINTER(C.c_uint32)]
+    L.orc_rand_f.restype = C.c_float
+    L.orc_sincosf.argtypes = [C.c_float, fp, fp]
+    L.orc_sincosf.restype = None
+    L.orc_f32_to_f16.argtypes = [C.c_float]
+    L.orc_f32_to_f16.restype = C.c_uint16
+    L.orc_f16_to_f32.argtypes = [C.c_uint16]
+    L.orc_f16_to_f32.restype = C.c_float
+    L.orc_ray_sphere_intersect.argtypes = [fp, fp, C.c_void_p, C.POINTER(OrcHit)]
+    L.orc_ray_sphere_intersect.restype = None
+    L.orc_ray_triangle_intersect.argtypes = [fp, fp, C.c_void_p, C.POINTER(OrcHit)]
+    L.orc_ray_triangle_intersect.restype = None
+    L.orc_ray_all.argtypes = [fp, fp, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(OrcHit)]
+    L.orc_ray_all.restype = None
+    L.orc_sample_light_triangles.argtypes = [fp, C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32, fp, fp, fp]
+    L.orc_sample_light_triangles.restype = C.c_float
+    L.orc_sample_cosine_hemisphere.argtypes = [fp, C.POINTER(C.c_uint32), fp]
+    L.orc_sample_cosine_hemisphere.restype = None
+    L.orc_primary_ray.argtypes = [C.c_void_p, C.c_int, C.c_int, fp, fp]
+    L.orc_primary_ray.restype = C.c_uint32
+    L.orc_ray_trace.argtypes = [fp, fp, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32,
+                                C.c_void_p, C.c_uint32, fp, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
+    L.orc_ray_trace.restype = None
+    L.orc_render_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
+                                   C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_render_frame.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def wang_hash(s: int) -> int:
+    return lib().orc_wang_hash(s & 0xFFFFFFFF)
+
+
+def rand_f(state: int):
+    st = C.c_uint32(state & 0xFFFFFFFF)
+    v = lib().orc_rand_f(C.byref(st))
+    return np.float32(v), st.value
+
+
+def sincos(x: float):
+    s, c = C.c_float(), C.c_float()
+    lib().orc_sincosf(float(np.float32(x)), C.byref(s), C.byref(c))
+    return np.float32(s.value), np.float32(c.value)
+
+
+def f32_to_f16(x: float) -> int:
+    return lib().orc_f32_to_f16(float(np.float32(x)))
+
+
+def f16_to_f32(h: int) -> np.float32:
+    return np.float32(lib().orc_f16_to_f32(h))
+
+
+def ray_sphere(origin, direction, sphere_rec: np.ndarray) -> OrcHit:
+    out = OrcHit()
+    rec = np.ascontiguousarray(sphere_rec, dtype=np.float32)
+    lib().orc_ray_sphere_intersect(_f3(origin), _f3(direction), _ptr(rec), C.byref(out))
+    return out
+
+
+def ray_triangle(origin, direction, tri_rec: np.ndarray) -> OrcHit:
+    out = OrcHit()
+    rec = np.ascontiguousarray(tri_rec, dtype=np.float32)
+    lib().orc_ray_triangle_intersect(_f3(origin), _f3(direction), _ptr(rec), C.byref(out))
+    return out
+
+
+def ray_all(origin, direction, spheres: np.ndarray, tris: np.ndarray) -> OrcHit:
+    out = OrcHit()
+    lib().orc_ray_all(_f3(origin), _f3(direction), _ptr(spheres), len(spheres), _ptr(tris), len(tris), C.byref(out))
+    return out
+
+
+def sample_light_triangles(hit_point, state: int, tris: np.ndarray):
+    st = C.c_uint32(state)
+    d, e, dist = (C.c_float * 3)(), (C.c_float * 3)(), C.c_float()
+    pdf = lib().orc_sample_light_triangles(_f3(hit_point), C.byref(st), _ptr(tris), len(tris), d, e, C.byref(dist))
+    return dict(direction=np.array(d[:], np.float32), emission=np.array(e[:], np.float32),
+                distance=np.float32(dist.value), pdf=np.float32(pdf), state=st.value)
+
+
+def sample_cosine_hemisphere(normal, state: int):
+    st = C.c_uint32(state)
+    out = (C.c_float * 3)()
+    lib().orc_sample_cosine_hemisphere(_f3(normal), C.byref(st), out)
+    return np.array(out[:], np.float32), st.value
+
+
+def primary_ray(uniforms: np.ndarray, px: int, py: int):
+    o, d = (C.c_float * 3)(), (C.c_float * 3)()
+    st = lib().orc_primary_ray(_ptr(uniforms), px, py, o, d)
+    return np.array(o[:], np.float32), np.array(d[:], np.float32), st
+
+
+def ray_trace(origin, direction, max_bounces: int, state: int, spheres, tris):
+    st = C.c_uint32(state)
+    out = (C.c_float * 3)()
+    n = C.c_uint64(0)
+    fid = C.c_int32(-1)
+    lib().orc_ray_trace(_f3(origin), _f3(direction), max_bounces, C.byref(st), _ptr(spheres), len(spheres),
+                        _ptr(tris), len(tris), out, C.byref(n), C.byref(fid))
+    return np.array(out[:], np.float32), st.value, n.value, fid.value
+
+
+class OracleRenderer:
+    """Frame-level driver with the renderer's sequencing
+    (src/webgpu-renderer.ts:237-268): frameIndex is incremented before each
+    frame; the accumulator planes persist; reset only zeroes frameIndex."""
+
+    def __init__(self, scene, width: int, height: int, max_bounces: int = 6, threads: int = 0,
+                 rect=None):
+        from raytracer_amd import scene as S
+
+        self._S = S
+        self.scene = scene
+        self.width, self.height = width, height
+        self.max_bounces = max_bounces
+        self.threads = threads or (os.cpu_count() or 1)
+        self.spheres = S.pack_spheres(scene.spheres)
+        self.tris = S.pack_triangles(scene.triangles)
+        self.rect = rect or (0, 0, width, height)
+        self.frame_index = 0
+        self.samples_per_pixel = 1
+        self.accum = np.zeros((3, height, width), dtype=np.float32)
+        self.frame_f16 = np.zeros((height, width, 4), dtype=np.uint16)
+        self.ids = np.full((height, width), -2, dtype=np.int32)
+        self.counters = np.zeros(4, dtype=np.uint64)
+
+    def set_samples_per_pixel(self, n: int):
+        self.samples_per_pixel = max(1, min(16, n))
+
+    def reset_accumulation(self):
+        self.frame_index = 0
+
+    def render(self):
+        self.frame_index += 1
+        u = self._S.pack_uniforms(self.scene.camera, self.frame_index, self.width, self.height,
+                                  self.samples_per_pixel)
+        x0, y0, x1, y1 = self.rect
+        rc = lib().orc_render_frame(_ptr(u), _ptr(self.spheres), len(self.spheres), _ptr(self.tris), len(self.tris),
+                                    self.max_bounces, x0, y0, x1, y1, _ptr(self.accum), _ptr(self.frame_f16),
+                                    _ptr(self.ids), _ptr(self.counters), self.threads)
+        if rc != 0:
+            raise RuntimeError("orc_render_frame failed: %d" % rc)
+
+    def render_frames(self, n: int):
+        for _ in range(n):
+            self.render()
+
+    def accum_rgb(self) -> np.ndarray:
+        """(H, W, 3) float32 view of the accumulator."""
+        return np.ascontiguousarray(np.transpose(self.accum, (1, 2, 0)))
