@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s and ms/frame of the HIP path tracer on
+scene_suzanne.json at 1920x1080, 16 spp per frame (BASELINE.json configs[2]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one frame: one pass of the path-trace + accumulate hot path over the
+image at 16 samples per pixel.  K timed steps (default 16 = 256 spp, the
+configuration the metric is quoted on).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the image rows are
+dealt to the ranks in 8-row stripes; each rank renders K*N frames of its
+stripes (so the work per GPU is that of the N = 1 run: weak scaling), no
+collective on the data path, and one RCCL all-gather of the accumulator rows
+at the end, inside the timed region.  The assembled image is bit-identical to
+what one GPU renders for the same K*N frames.
+
+Rank 0 prints one JSON line.  ``roofline`` prices the path-trace kernel against
+the FP32 vector peak (this path has no matrix work); ``cpu_baseline`` times the
+CPU oracle (a plain-C restatement of the reference shader) on a bounded band
+of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+SCENE = "suzanne"
+WIDTH, HEIGHT, SPP, MAX_BOUNCES = 1920, 1080, 16, 6
+PEAK_FP32_TFLOPS = 157.3  # MI355X FP32 vector peak (packed FMA), chip-level spec
+# algorithmic flop prices per test / per bounce ("Roofline accounting")
+F_BOX, F_TRI, F_SPH, F_SHADE = 24, 52, 31, 160
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU baseline band (0 = auto)")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene, threads):
+    """Times the CPU oracle on a band of frame 1 (same scene, resolution, spp)."""
+    from tests import oracle_lib as O
+
+    def run(y0, y1):
+        orc = O.OracleRenderer(scene, WIDTH, HEIGHT, max_bounces=MAX_BOUNCES, threads=threads, rect=(0, y0, WIDTH, y1))
+        orc.set_samples_per_pixel(SPP)
+        t = time.perf_counter()
+        orc.render()
+        return int(orc.counters[0]), time.perf_counter() - t
+
+    # calibrate on 2 rows, then size the band for about 15 s
+    rays, dt = run(540, 542)
+    rate = rays / max(dt, 1e-6)
+    rows = int(max(2, min(HEIGHT // 2, round(15.0 * rate / (rays / 2.0)))))
+    y0 = (HEIGHT - rows) // 2
+    rays, dt = run(y0, y0 + rows)
+    return {
+        "value": rays / dt / 1e6,
+        "unit": "Mrays/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "rows %d..%d of frame 1 (%d of %d pixels), %d spp, %d rays in %.1f s"
+                  % (y0, y0 + rows, rows * WIDTH, WIDTH * HEIGHT, SPP, rays, dt),
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    from raytracer_amd import capi
+    from raytracer_amd import scene as S
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus must equal WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the renderer)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    scene = S.load_scene(S.scene_path(SCENE))
+    spheres, tris = S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles)
+    ctx = capi.Context(WIDTH, HEIGHT, device=local_rank, stripe_rows=8, stripe_index=rank, stripe_count=world)
+    ctx.set_max_bounces(MAX_BOUNCES)
+    ctx.set_scene(spheres, tris)
+    ctx.set_uniforms(S.pack_uniforms(scene.camera, 1, WIDTH, HEIGHT, SPP))
+
+    frames_per_step = world  # weak scaling: every rank keeps the N = 1 amount of work
+    K, W = args.steps, args.warmup
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    gather_buf = None
+    own = ctx.owned_rows()
+    if world > 1:
+        gather_buf = torch.empty(3 * own * WIDTH, dtype=torch.float32, device="cuda")
+
+    # warmup (frames 1..W*frames_per_step), then the accumulator restarts at frame 1
+    if W > 0:
+        ctx.render_frames(1, W * frames_per_step)
+    barrier()
+
+    rays_before = int(ctx.read_counters()[0])
+    kernel_ms = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    ctx.render_frames(1, K * frames_per_step)
+    if world > 1:
+        # combine: every rank contributes its rows; rank 0 assembles the image
+        ctx.export_owned_rows(gather_buf.data_ptr())
+        ctx.sync()
+        rows = torch.tensor([own], device="cuda")
+        all_rows = [torch.zeros_like(rows) for _ in range(world)]
+        dist.all_gather(all_rows, rows)
+        bufs = [torch.empty(3 * int(r.item()) * WIDTH, dtype=torch.float32, device="cuda") for r in all_rows]
+        dist.all_gather(bufs, gather_buf)
+        if rank == 0:
+            for src, b in enumerate(bufs):
+                if src != 0:
+                    ctx.import_rows(b.data_ptr(), src)
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = ctx.last_render_ms()
+    rays = int(ctx.read_counters()[0]) - rays_before
+
+    t = torch.tensor([dt, float(rays), kernel_ms], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, kernel_ms, rays = float(tmax[0]), float(tmax[2]), int(tsum[1])
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # roofline: algorithmic flops of the timed launches / HIP-event time of those launches
+    cctx = capi.Context(WIDTH, HEIGHT, device=local_rank)
+    cctx.set_max_bounces(MAX_BOUNCES)
+    cctx.set_scene(spheres, tris)
+    cctx.set_counting(True)
+    cctx.set_uniforms(S.pack_uniforms(scene.camera, 1, WIDTH, HEIGHT, SPP))
+    cctx.render_frame()
+    cnt = [int(x) for x in cctx.read_counters()]
+    cctx.close()
+    c_rays, c_boxpairs, c_tris, c_sph, c_bounces = cnt[0], cnt[1], cnt[2], cnt[3], cnt[4]
+    flops_per_ray = (2 * c_boxpairs * F_BOX + c_tris * F_TRI + c_sph * F_SPH + c_bounces * F_SHADE) / c_rays
+    brute_flops_per_ray = F_SPH * len(spheres) + F_TRI * len(tris)
+    rays_per_launch = rays / world / (K * frames_per_step)
+    launch_ms = kernel_ms / (K * frames_per_step)
+    achieved = flops_per_ray * rays_per_launch / (launch_ms * 1e-3) / 1e12
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "Mrays/s",
+        "value": rays / dt / 1e6,
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": dt * 1e3 / K,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "reference scene file scene_suzanne.json + models/suzanne_500_tris.obj (982 triangles, 1 sphere); no random inputs",
+        "config": {
+            "workload": "scene_suzanne.json 1920x1080, %d frames x %d spp, max bounces %d, BVH traversal%s"
+                        % (K * frames_per_step, SPP, MAX_BOUNCES,
+                           "" if world == 1 else ", rows dealt to %d GPUs in 8-row stripes + RCCL all-gather" % world),
+            "frames": K * frames_per_step,
+            "spp_per_frame": SPP,
+            "ms_per_frame": dt * 1e3 / (K * frames_per_step),
+            "rays": rays,
+        },
+        "roofline": {
+            "bound": "valu_fp32",
+            "achieved": achieved,
+            "peak": PEAK_FP32_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_TFLOPS,
+            "traffic": traffic,
+            "kernel": "path-trace + accumulate launch (one frame)",
+            "kernel_ms_per_launch": launch_ms,
+            "flops_per_ray": flops_per_ray,
+            "rays_per_launch": rays_per_launch,
+            "per_ray": {"box_tests": 2 * c_boxpairs / c_rays, "triangle_tests": c_tris / c_rays,
+                        "sphere_tests": c_sph / c_rays, "bounces": c_bounces / c_rays},
+            "brute_force_equivalent": {"flops_per_ray": brute_flops_per_ray,
+                                       "tflops": brute_flops_per_ray * rays_per_launch / (launch_ms * 1e-3) / 1e12},
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+        out["cpu_baseline"] = cpu_baseline(scene, threads)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

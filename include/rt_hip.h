@@ -1,0 +1,190 @@
+/*
+ * rt_hip.h -- C ABI of the MI355X (gfx950) renderer backend, librt_hip.so.
+ *
+ * The reference (guymor4/raytracer) has no FFI layer: its renderer talks to the
+ * GPU through the WebGPU objects created in src/webgpu-renderer.ts and
+ * src/accumulator.ts.  Each entry point below replaces one of those WebGPU
+ * interactions; the comment on it names the lines it stands in for.  The N-API
+ * addon (raytracer_amd/js/addon) and the ctypes binding
+ * (raytracer_amd/capi.py) bind exactly these symbols.
+ *
+ * Conventions
+ *   - every call returns 0 on success, a negative rt_status otherwise;
+ *     rt_last_error() returns the message of the calling thread's last failure;
+ *   - the caller owns every host buffer it passes, the library owns all device
+ *     memory; buffers use the reference's byte layouts verbatim
+ *     (src/gpu-schemas.ts: Sphere 64 B stride, Triangle 96 B stride,
+ *     Uniforms 80 B);
+ *   - one context lives on one GPU; calls on one context must be serialised by
+ *     the caller (the reference drives its renderer from one JS thread);
+ *   - rendering calls are asynchronous on the context's HIP stream; the read
+ *     calls and rt_sync() wait for it.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_context rt_context;
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,   /* bad argument or call order            */
+    RT_ERR_DEVICE = -2,    /* HIP runtime error (no GPU, OOM, ...)  */
+    RT_ERR_UNSUPPORTED = -3
+} rt_status;
+
+/* Traversal used by rt_render_frame. */
+typedef enum rt_mode {
+    RT_MODE_BVH = 0,        /* bounding-volume hierarchy traversal (default)          */
+    RT_MODE_BRUTE_FORCE = 1 /* every primitive per ray, the reference's own ray_all   */
+} rt_mode;
+
+/* Message of the last failure on the calling thread ("" if none). */
+const char *rt_last_error(void);
+
+/* Number of HIP devices visible to the process (0 if none / no driver). */
+int rt_device_count(void);
+
+/*
+ * Create a renderer for a width x height image on HIP device `device`.
+ * Replaces WebGPURenderer.Create's adapter/device/texture/buffer set-up
+ * (src/webgpu-renderer.ts:48-118,141-212) and Accumulator.create's three
+ * r32float planes (src/accumulator.ts:39-46).  The accumulator planes start
+ * zeroed, frame counters start at 0.
+ *
+ * The context renders the rows y with (y / stripe_rows) % stripe_count ==
+ * stripe_index; other rows are never touched.  stripe_count = 1 renders the
+ * whole image (stripe_rows is then ignored; pass 8).
+ */
+int rt_create(int device, int width, int height,
+              int stripe_rows, int stripe_index, int stripe_count,
+              rt_context **out);
+
+/* Frees all device memory of the context.  The reference never destroys its
+ * renderer; a scene switch builds a new one (src/main.ts:31-35). */
+void rt_destroy(rt_context *ctx);
+
+/*
+ * Upload the scene.  Replaces the spheres/triangles storage-buffer creation and
+ * writes of src/webgpu-renderer.ts:157-188.  `spheres` holds n_spheres records
+ * of 64 bytes, `triangles` n_triangles records of 96 bytes; either count may
+ * be 0 (then the pointer may be NULL).  Builds the acceleration structure and
+ * the emissive-triangle table on the host; may be called again to replace the
+ * scene.
+ */
+int rt_set_scene(rt_context *ctx,
+                 const void *spheres, uint32_t n_spheres,
+                 const void *triangles, uint32_t n_triangles);
+
+/*
+ * Replace the 80-byte Uniforms blob.  Stands in for
+ * WebGPURenderer.writeUniforms (src/webgpu-renderer.ts:214-230).  resolution
+ * must equal the context's width/height; samplesPerPixel must be >= 1.
+ */
+int rt_set_uniforms(rt_context *ctx, const void *uniforms80);
+
+/* The shader constant maxBounceCount (public/raytracer_compute.wgsl:331);
+ * default 6. */
+int rt_set_max_bounces(rt_context *ctx, uint32_t max_bounces);
+
+/* Select the traversal (default RT_MODE_BVH).  Both produce identical output. */
+int rt_set_mode(rt_context *ctx, int mode);
+
+/*
+ * Render one frame with the current uniforms: the compute pass
+ * (dispatchWorkgroups, src/webgpu-renderer.ts:253-260) followed by the
+ * accumulator pass (src/accumulator.ts:63-78), as one submission
+ * (src/webgpu-renderer.ts:267).  Asynchronous.
+ */
+int rt_render_frame(rt_context *ctx);
+
+/*
+ * Render n_frames frames with frameIndex = first_frame_index,
+ * first_frame_index + 1, ... (all other uniforms as last set), i.e. n_frames
+ * iterations of WebGPURenderer.render's body after its frameIndex++
+ * (src/webgpu-renderer.ts:248-267).  The stored uniforms' frameIndex ends at
+ * the last rendered index.  Asynchronous.
+ */
+int rt_render_frames(rt_context *ctx, uint32_t first_frame_index, uint32_t n_frames);
+
+/* Wait for all submitted work of the context. */
+int rt_sync(rt_context *ctx);
+
+/* Milliseconds the GPU spent in the most recent rt_render_frame /
+ * rt_render_frames call (HIP events on the context's stream); waits for it. */
+int rt_last_render_ms(rt_context *ctx, float *ms);
+
+/*
+ * Read back the accumulator (the three r32float planes of
+ * src/accumulator.ts:39-46, which the reference only ever shows on the
+ * canvas) as width*height interleaved RGB float32.  Rows the context does not
+ * own read as 0.
+ */
+int rt_read_accum(rt_context *ctx, float *rgb);
+
+/* Read back the last frame's rgba16float intermediate texture
+ * (src/webgpu-renderer.ts:108-112): width*height*4 half-float bit patterns. */
+int rt_read_frame_f16(rt_context *ctx, uint16_t *rgba);
+
+/*
+ * Read back the last frame's primary-hit ids, width*height int32: the index of
+ * the object the first ray_all call of the pixel returned, in ray_all's
+ * iteration order (public/raytracer_compute.wgsl:15-39): spheres 0..S-1,
+ * triangles S..S+T-1, miss -1.  Rows not owned read as -2.  The reference's
+ * HitInfo carries no id; this output exists for parity checks.
+ */
+int rt_read_primary_ids(rt_context *ctx, int32_t *ids);
+
+/*
+ * Cumulative 64-bit counters since creation:
+ *   [0] rays traced (calls of the reference's ray_all: closest-hit + shadow)
+ *   [1] node visits (each tests the two child boxes of one node)
+ *   [2] triangle tests   [3] sphere tests   [4] bounces (shaded hits)
+ *   [5..7] reserved, 0
+ * [1..4] advance only while counting is enabled (rt_set_counting), which
+ * selects an instrumented build of the same kernel; timings are taken with
+ * counting off.  [0] always advances.
+ */
+int rt_read_counters(rt_context *ctx, uint64_t counters[8]);
+int rt_set_counting(rt_context *ctx, int enable);
+
+/*
+ * The reference's performance counter: performance_counters[0] accumulates
+ * arrayLength(&triangles) per ray_all call in a u32
+ * (public/raytracer_compute.wgsl:27) and
+ * WebGPURenderer.getTriangleTestsSinceLastCheck returns it and zeroes it
+ * (src/webgpu-renderer.ts:301-321).  Returns the same value, wrapped modulo
+ * 2^32 as the reference's u32 does, since the previous call.
+ */
+int rt_take_triangle_tests(rt_context *ctx, uint32_t *triangle_tests);
+
+/*
+ * Multi-GPU support (no counterpart in the reference, which uses one GPU).
+ * rt_owned_rows: number of image rows this context renders.
+ * rt_export_owned_rows: copy the accumulator rows the context owns, in
+ *   increasing y, into device memory `dst` as three planes of
+ *   owned_rows*width float32 (R plane, G plane, B plane), on the context's
+ *   stream.  `dst` must be device memory on the context's GPU (for instance a
+ *   torch tensor's data_ptr) of 3*owned_rows*width*4 bytes.
+ * rt_import_rows: inverse for a gathered image: scatter such a block that
+ *   came from the context with stripe_index `from_index` into this context's
+ *   accumulator planes (used on the rank that assembles the full image).
+ */
+int rt_owned_rows(rt_context *ctx, int *rows);
+int rt_export_owned_rows(rt_context *ctx, void *dst_device);
+int rt_import_rows(rt_context *ctx, const void *src_device, int from_index);
+
+/* Acceleration-structure statistics of the current scene, for reports:
+ * out[0] nodes, out[1] leaves, out[2] max depth, out[3] bytes on device. */
+int rt_scene_stats(rt_context *ctx, uint64_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

@@ -1,0 +1,174 @@
+"""ctypes binding of librt_hip.so (the C ABI declared in include/rt_hip.h).
+
+There is no fallback: if the library is missing or no GPU is usable the calls
+raise ``RtError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+
+RT_MODE_BVH = 0
+RT_MODE_BRUTE_FORCE = 1
+
+# name -> (restype, argtypes); must list every symbol include/rt_hip.h declares
+SYMBOLS = {
+    "rt_last_error": (C.c_char_p, []),
+    "rt_device_count": (C.c_int, []),
+    "rt_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "rt_destroy": (None, [C.c_void_p]),
+    "rt_set_scene": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
+    "rt_set_uniforms": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_set_max_bounces": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rt_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_set_counting": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_render_frame": (C.c_int, [C.c_void_p]),
+    "rt_render_frames": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "rt_sync": (C.c_int, [C.c_void_p]),
+    "rt_last_render_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "rt_read_accum": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_read_frame_f16": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_read_primary_ids": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_read_counters": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_take_triangle_tests": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "rt_owned_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "rt_export_owned_rows": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_import_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "rt_scene_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
+}
+
+
+class RtError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load librt_hip.so and declare every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtError("librt_hip.so is not built (run __graft_entry__.build() or make -C raytracer_amd/csrc)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        msg = load().rt_last_error()
+        raise RtError("rt_hip error %d: %s" % (rc, msg.decode() if msg else ""))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """Thin object wrapper over one ``rt_context``."""
+
+    def __init__(self, width: int, height: int, device: int = 0, stripe_rows: int = 8,
+                 stripe_index: int = 0, stripe_count: int = 1):
+        self.lib = load()
+        self.width, self.height = width, height
+        self.handle = C.c_void_p()
+        _check(self.lib.rt_create(device, width, height, stripe_rows, stripe_index, stripe_count,
+                                  C.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            self.lib.rt_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_scene(self, spheres: np.ndarray, triangles: np.ndarray):
+        spheres = np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1, 16)
+        triangles = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 24)
+        _check(self.lib.rt_set_scene(self.handle, _ptr(spheres) if len(spheres) else None, len(spheres),
+                                     _ptr(triangles) if len(triangles) else None, len(triangles)))
+
+    def set_uniforms(self, uniforms: np.ndarray):
+        u = np.ascontiguousarray(uniforms, dtype=np.float32)
+        assert u.nbytes == 80
+        _check(self.lib.rt_set_uniforms(self.handle, _ptr(u)))
+
+    def set_max_bounces(self, n: int):
+        _check(self.lib.rt_set_max_bounces(self.handle, n))
+
+    def set_mode(self, mode: int):
+        _check(self.lib.rt_set_mode(self.handle, mode))
+
+    def set_counting(self, enable: bool):
+        _check(self.lib.rt_set_counting(self.handle, 1 if enable else 0))
+
+    def render_frame(self):
+        _check(self.lib.rt_render_frame(self.handle))
+
+    def render_frames(self, first_frame_index: int, n: int):
+        _check(self.lib.rt_render_frames(self.handle, first_frame_index, n))
+
+    def sync(self):
+        _check(self.lib.rt_sync(self.handle))
+
+    def last_render_ms(self) -> float:
+        ms = C.c_float()
+        _check(self.lib.rt_last_render_ms(self.handle, C.byref(ms)))
+        return ms.value
+
+    def read_accum(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        _check(self.lib.rt_read_accum(self.handle, _ptr(out)))
+        return out
+
+    def read_frame_f16(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 4), dtype=np.uint16)
+        _check(self.lib.rt_read_frame_f16(self.handle, _ptr(out)))
+        return out
+
+    def read_primary_ids(self) -> np.ndarray:
+        out = np.empty((self.height, self.width), dtype=np.int32)
+        _check(self.lib.rt_read_primary_ids(self.handle, _ptr(out)))
+        return out
+
+    def read_counters(self) -> np.ndarray:
+        out = np.zeros(8, dtype=np.uint64)
+        _check(self.lib.rt_read_counters(self.handle, _ptr(out)))
+        return out
+
+    def take_triangle_tests(self) -> int:
+        v = C.c_uint32()
+        _check(self.lib.rt_take_triangle_tests(self.handle, C.byref(v)))
+        return v.value
+
+    def owned_rows(self) -> int:
+        v = C.c_int()
+        _check(self.lib.rt_owned_rows(self.handle, C.byref(v)))
+        return v.value
+
+    def export_owned_rows(self, device_ptr: int):
+        _check(self.lib.rt_export_owned_rows(self.handle, C.c_void_p(device_ptr)))
+
+    def import_rows(self, device_ptr: int, from_index: int):
+        _check(self.lib.rt_import_rows(self.handle, C.c_void_p(device_ptr), from_index))
+
+    def scene_stats(self) -> dict:
+        out = np.zeros(4, dtype=np.uint64)
+        _check(self.lib.rt_scene_stats(self.handle, _ptr(out)))
+        return dict(nodes=int(out[0]), leaves=int(out[1]), max_depth=int(out[2]), device_bytes=int(out[3]))

@@ -1,0 +1,529 @@
+// rt_hip.hip -- HIP kernels and the C ABI (include/rt_hip.h) of the MI355X
+// renderer backend.  gfx950 only; build with -ffp-contract=off (see rt_core.h).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "rt_core.h"
+#include "rt_pixel.h"
+#include "rt_scene.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define RT_HIP_CHECK(expr)                                                                       \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+// Which image rows a context renders: local row l maps to global row
+// ((l / rows) * count + index) * rows + l % rows  (8-row stripes dealt round-robin).
+struct StripeMap {
+    int rows, index, count;
+};
+
+__host__ __device__ inline int stripe_global_row(const StripeMap &m, int local)
+{
+    return ((local / m.rows) * m.count + m.index) * m.rows + local % m.rows;
+}
+
+// ---------------------------------------------------------------------------
+// Per-lane traversal stack in LDS: entry k of lane l lives at base[k * BLOCK + l],
+// so one wave's pushes/pops touch 64 consecutive dwords (no bank conflicts).
+// ---------------------------------------------------------------------------
+template <int BLOCK>
+struct LdsStack {
+    int32_t *base;
+    int sp;
+    __device__ void reset() { sp = 0; }
+    __device__ void push(int32_t v) { base[sp * BLOCK] = v; sp++; }
+    __device__ int32_t pop() { sp--; return base[sp * BLOCK]; }
+    __device__ bool empty() const { return sp == 0; }
+};
+
+__device__ inline uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+struct FrameBuffers {
+    float *accum;        // 3 planes of width*height f32
+    uint16_t *frame_f16; // width*height*4 half bits
+    int32_t *ids;        // width*height
+    unsigned long long *counters;
+};
+
+// rgba16float store + accumulator.wgsl:44-68 for one pixel.
+__device__ inline void store_pixel(const rt::FrameParams &fp, const FrameBuffers &fb, int px, int py, rt::f3 color,
+                                   int32_t primary_id)
+{
+    size_t p = (size_t)py * (size_t)fp.width + (size_t)px;
+    size_t plane = (size_t)fp.width * (size_t)fp.height;
+    uint16_t hr = rt::f32_to_f16_bits(color.x), hg = rt::f32_to_f16_bits(color.y), hb = rt::f32_to_f16_bits(color.z);
+    uint2 packed;
+    packed.x = (uint32_t)hr | ((uint32_t)hg << 16);
+    packed.y = (uint32_t)hb | (0x3c00u << 16);
+    reinterpret_cast<uint2 *>(fb.frame_f16)[p] = packed;
+    fb.ids[p] = primary_id;
+    fb.accum[p] = rt::accumulate_channel(fb.accum[p], rt::f16_bits_to_f32(hr), fp.frame_f);
+    fb.accum[plane + p] = rt::accumulate_channel(fb.accum[plane + p], rt::f16_bits_to_f32(hg), fp.frame_f);
+    fb.accum[2 * plane + p] = rt::accumulate_channel(fb.accum[2 * plane + p], rt::f16_bits_to_f32(hb), fp.frame_f);
+}
+
+// ---------------------------------------------------------------------------
+// Kernel A: one thread per pixel, the shader's own loop nest
+// (raytracer_compute.wgsl:280-341), one wave per 8x8 pixel tile as the
+// reference's @workgroup_size(8, 8); four tiles per 256-thread block.
+// ---------------------------------------------------------------------------
+constexpr int kBlock = 256;
+
+template <bool BRUTE, int STACK, bool COUNT>
+__global__ __launch_bounds__(kBlock) void render_tiles_kernel(rt::SceneView sc, rt::FrameParams fp, StripeMap sm,
+                                                               int local_rows, FrameBuffers fb)
+{
+    __shared__ int32_t lds_stack[BRUTE ? 1 : STACK * kBlock];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile_x = blockIdx.x * 4 + wave;
+    const int px = tile_x * 8 + (lane & 7);
+    const int ly = blockIdx.y * 8 + (lane >> 3);
+    uint32_t n_rays = 0;
+    rt::TestCounts cnt = {0, 0, 0, 0};
+    if (px < fp.width && ly < local_rows) {
+        const int py = stripe_global_row(sm, ly);
+        if (py < fp.height) {
+            LdsStack<kBlock> stack;
+            stack.base = lds_stack + threadIdx.x;
+            stack.sp = 0;
+            int32_t pid;
+            rt::f3 color = rt::render_pixel<BRUTE>(sc, fp, px, py, stack, n_rays, pid, COUNT ? &cnt : nullptr);
+            store_pixel(fp, fb, px, py, color, pid);
+        }
+    }
+    uint32_t total = wave_sum(n_rays);
+    if (lane == 0 && total) atomicAdd(fb.counters, (unsigned long long)total);
+    if (COUNT) {
+        uint32_t b = wave_sum(cnt.boxes), t = wave_sum(cnt.tris), s = wave_sum(cnt.spheres), h = wave_sum(cnt.bounces);
+        if (lane == 0) {
+            atomicAdd(fb.counters + 1, (unsigned long long)b);
+            atomicAdd(fb.counters + 2, (unsigned long long)t);
+            atomicAdd(fb.counters + 3, (unsigned long long)s);
+            atomicAdd(fb.counters + 4, (unsigned long long)h);
+        }
+    }
+}
+
+__global__ void fill_i32_kernel(int32_t *p, int32_t v, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// rows of the three planes <-> a dense block of owned rows
+__global__ void export_rows_kernel(const float *accum, float *dst, int width, int height, int local_rows, StripeMap sm)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t n = (size_t)local_rows * width;
+    if (i >= n) return;
+    int ly = (int)(i / width), x = (int)(i % width);
+    int y = stripe_global_row(sm, ly);
+    size_t plane = (size_t)width * height;
+    for (int c = 0; c < 3; c++) dst[c * n + i] = accum[c * plane + (size_t)y * width + x];
+}
+
+__global__ void import_rows_kernel(float *accum, const float *src, int width, int height, int local_rows, StripeMap sm)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t n = (size_t)local_rows * width;
+    if (i >= n) return;
+    int ly = (int)(i / width), x = (int)(i % width);
+    int y = stripe_global_row(sm, ly);
+    size_t plane = (size_t)width * height;
+    for (int c = 0; c < 3; c++) accum[c * plane + (size_t)y * width + x] = src[c * n + i];
+}
+
+int owned_rows_of(int height, const StripeMap &m)
+{
+    int n = 0;
+    for (int y = 0; y < height; y++)
+        if ((y / m.rows) % m.count == m.index) n++;
+    return n;
+}
+
+template <class T>
+int upload(const std::vector<T> &v, T **dptr, hipStream_t s)
+{
+    *dptr = nullptr;
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    RT_HIP_CHECK(hipMalloc((void **)dptr, bytes));
+    if (!v.empty()) RT_HIP_CHECK(hipMemcpyAsync(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return RT_OK;
+}
+
+} // namespace
+
+struct rt_context {
+    int device = 0;
+    int width = 0, height = 0;
+    StripeMap sm{8, 0, 1};
+    int local_rows = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+
+    FrameBuffers fb{nullptr, nullptr, nullptr, nullptr};
+
+    // scene
+    rt::BuiltScene host_scene;
+    rt::SceneView view{};
+    rt::f4 *d_nodes = nullptr, *d_tri_isect = nullptr, *d_tri_shade = nullptr, *d_tri_raw = nullptr, *d_spheres = nullptr,
+           *d_lights = nullptr;
+    bool has_scene = false;
+    size_t scene_bytes = 0;
+
+    float uniforms[20] = {0};
+    bool has_uniforms = false;
+    uint32_t max_bounces = 6;
+    int mode = RT_MODE_BVH;
+    bool counting = false;
+    unsigned long long tests_taken_rays = 0; // rays already reported by rt_take_triangle_tests
+
+    void free_scene()
+    {
+        for (rt::f4 *p : {d_nodes, d_tri_isect, d_tri_shade, d_tri_raw, d_spheres, d_lights}) (void)hipFree(p);
+        d_nodes = d_tri_isect = d_tri_shade = d_tri_raw = d_spheres = d_lights = nullptr;
+        has_scene = false;
+    }
+};
+
+namespace {
+
+int launch_frame(rt_context *c, const rt::FrameParams &fp)
+{
+    dim3 block(kBlock);
+    dim3 grid((c->width + 31) / 32, (c->local_rows + 7) / 8);
+    if (grid.x == 0 || grid.y == 0) return RT_OK;
+    uint32_t depth = c->host_scene.max_depth;
+#define RT_LAUNCH_A(BRUTE, STACK, COUNT)                                                                        \
+    hipLaunchKernelGGL((render_tiles_kernel<BRUTE, STACK, COUNT>), grid, block, 0, c->stream, c->view, fp, c->sm, \
+                       c->local_rows, c->fb)
+    if (c->mode == RT_MODE_BRUTE_FORCE) {
+        RT_LAUNCH_A(true, 1, false);
+    } else if (c->counting) {
+        if (depth < 16) RT_LAUNCH_A(false, 16, true);
+        else if (depth < 32) RT_LAUNCH_A(false, 32, true);
+        else RT_LAUNCH_A(false, 64, true);
+    } else {
+        if (depth < 16) RT_LAUNCH_A(false, 16, false);
+        else if (depth < 32) RT_LAUNCH_A(false, 32, false);
+        else RT_LAUNCH_A(false, 64, false);
+    }
+#undef RT_LAUNCH_A
+    RT_HIP_CHECK(hipGetLastError());
+    return RT_OK;
+}
+
+int check_ready(rt_context *c)
+{
+    if (!c) return fail(RT_ERR_INVALID, "null context");
+    if (!c->has_scene) return fail(RT_ERR_INVALID, "rt_set_scene has not been called");
+    if (!c->has_uniforms) return fail(RT_ERR_INVALID, "rt_set_uniforms has not been called");
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_last_error.c_str(); }
+
+int rt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rt_create(int device, int width, int height, int stripe_rows, int stripe_index, int stripe_count, rt_context **out)
+{
+    if (!out) return fail(RT_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (width < 1 || height < 1 || width > 65536 || height > 65536) return fail(RT_ERR_INVALID, "width/height out of range");
+    if (stripe_count < 1 || stripe_index < 0 || stripe_index >= stripe_count || stripe_rows < 1)
+        return fail(RT_ERR_INVALID, "bad stripe assignment");
+    int n_dev = 0;
+    RT_HIP_CHECK(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev) return fail(RT_ERR_DEVICE, "no such HIP device");
+    RT_HIP_CHECK(hipSetDevice(device));
+
+    rt_context *c = new (std::nothrow) rt_context();
+    if (!c) return fail(RT_ERR_DEVICE, "out of host memory");
+    c->device = device;
+    c->width = width;
+    c->height = height;
+    c->sm = StripeMap{stripe_rows, stripe_index, stripe_count};
+    c->local_rows = owned_rows_of(height, c->sm);
+
+    size_t px = (size_t)width * height;
+    auto cleanup = [&](int code) { rt_destroy(c); return code; };
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev_start)) != hipSuccess || (e = hipEventCreate(&c->ev_stop)) != hipSuccess ||
+        (e = hipMalloc((void **)&c->fb.accum, px * 3 * sizeof(float))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->fb.frame_f16, px * 4 * sizeof(uint16_t))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->fb.ids, px * sizeof(int32_t))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->fb.counters, 8 * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMemsetAsync(c->fb.accum, 0, px * 3 * sizeof(float), c->stream)) != hipSuccess ||
+        (e = hipMemsetAsync(c->fb.frame_f16, 0, px * 4 * sizeof(uint16_t), c->stream)) != hipSuccess ||
+        (e = hipMemsetAsync(c->fb.counters, 0, 8 * sizeof(unsigned long long), c->stream)) != hipSuccess) {
+        return cleanup(fail(RT_ERR_DEVICE, std::string("rt_create: ") + hipGetErrorString(e)));
+    }
+    hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, c->stream, c->fb.ids, -2, px);
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess)
+        return cleanup(fail(RT_ERR_DEVICE, std::string("rt_create: ") + hipGetErrorString(e)));
+    *out = c;
+    return RT_OK;
+}
+
+void rt_destroy(rt_context *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->free_scene();
+    (void)hipFree(c->fb.accum); (void)hipFree(c->fb.frame_f16); (void)hipFree(c->fb.ids); (void)hipFree(c->fb.counters);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rt_set_scene(rt_context *c, const void *spheres, uint32_t n_spheres, const void *triangles, uint32_t n_triangles)
+{
+    if (!c) return fail(RT_ERR_INVALID, "null context");
+    if ((n_spheres && !spheres) || (n_triangles && !triangles)) return fail(RT_ERR_INVALID, "null scene buffer");
+    if (n_triangles >= (1u << 28)) return fail(RT_ERR_UNSUPPORTED, "too many triangles");
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    RT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->free_scene();
+    rt::BuildOptions opt;
+    rt::build_scene(spheres, n_spheres, triangles, n_triangles, opt, c->host_scene);
+    if (c->host_scene.max_depth >= 64) return fail(RT_ERR_UNSUPPORTED, "acceleration structure too deep");
+    const rt::BuiltScene &hs = c->host_scene;
+    int rc;
+    if ((rc = upload(hs.nodes, &c->d_nodes, c->stream)) || (rc = upload(hs.tri_isect, &c->d_tri_isect, c->stream)) ||
+        (rc = upload(hs.tri_shade, &c->d_tri_shade, c->stream)) || (rc = upload(hs.tri_raw, &c->d_tri_raw, c->stream)) ||
+        (rc = upload(hs.spheres, &c->d_spheres, c->stream)) || (rc = upload(hs.lights, &c->d_lights, c->stream))) {
+        c->free_scene();
+        return rc;
+    }
+    RT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->scene_bytes = (hs.nodes.size() + hs.tri_isect.size() + hs.tri_shade.size() + hs.spheres.size() + hs.lights.size()) * sizeof(rt::f4);
+    rt::SceneView &v = c->view;
+    v.nodes = c->d_nodes; v.tri_isect = c->d_tri_isect; v.tri_shade = c->d_tri_shade; v.tri_raw = c->d_tri_raw;
+    v.spheres = c->d_spheres; v.lights = c->d_lights;
+    v.n_spheres = hs.n_spheres; v.n_tris = hs.n_tris; v.n_lights = hs.n_lights; v.n_lights_pass1 = hs.n_lights_pass1;
+    v.total_power = hs.total_power; v.root = hs.root;
+    c->has_scene = true;
+    return RT_OK;
+}
+
+int rt_set_uniforms(rt_context *c, const void *uniforms80)
+{
+    if (!c || !uniforms80) return fail(RT_ERR_INVALID, "null argument");
+    rt::FrameParams fp;
+    std::string err;
+    if (!rt::make_frame_params(uniforms80, c->max_bounces, fp, err)) return fail(RT_ERR_INVALID, err);
+    if (fp.width != c->width || fp.height != c->height)
+        return fail(RT_ERR_INVALID, "uniforms.resolution differs from the context's width/height");
+    std::memcpy(c->uniforms, uniforms80, 80);
+    c->has_uniforms = true;
+    return RT_OK;
+}
+
+int rt_set_max_bounces(rt_context *c, uint32_t max_bounces)
+{
+    if (!c) return fail(RT_ERR_INVALID, "null context");
+    c->max_bounces = max_bounces;
+    return RT_OK;
+}
+
+int rt_set_mode(rt_context *c, int mode)
+{
+    if (!c) return fail(RT_ERR_INVALID, "null context");
+    if (mode != RT_MODE_BVH && mode != RT_MODE_BRUTE_FORCE) return fail(RT_ERR_INVALID, "unknown mode");
+    c->mode = mode;
+    return RT_OK;
+}
+
+int rt_render_frames(rt_context *c, uint32_t first_frame_index, uint32_t n_frames)
+{
+    int rc = check_ready(c);
+    if (rc) return rc;
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    RT_HIP_CHECK(hipEventRecord(c->ev_start, c->stream));
+    for (uint32_t k = 0; k < n_frames; k++) {
+        c->uniforms[12] = (float)(first_frame_index + k);
+        rt::FrameParams fp;
+        std::string err;
+        if (!rt::make_frame_params(c->uniforms, c->max_bounces, fp, err)) return fail(RT_ERR_INVALID, err);
+        if ((rc = launch_frame(c, fp))) return rc;
+    }
+    RT_HIP_CHECK(hipEventRecord(c->ev_stop, c->stream));
+    c->timed = true;
+    return RT_OK;
+}
+
+int rt_render_frame(rt_context *c)
+{
+    int rc = check_ready(c);
+    if (rc) return rc;
+    return rt_render_frames(c, (uint32_t)c->uniforms[12], 1);
+}
+
+int rt_sync(rt_context *c)
+{
+    if (!c) return fail(RT_ERR_INVALID, "null context");
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    RT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_last_render_ms(rt_context *c, float *ms)
+{
+    if (!c || !ms) return fail(RT_ERR_INVALID, "null argument");
+    if (!c->timed) return fail(RT_ERR_INVALID, "nothing rendered yet");
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    RT_HIP_CHECK(hipEventSynchronize(c->ev_stop));
+    RT_HIP_CHECK(hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    return RT_OK;
+}
+
+int rt_read_accum(rt_context *c, float *rgb)
+{
+    if (!c || !rgb) return fail(RT_ERR_INVALID, "null argument");
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    size_t px = (size_t)c->width * c->height;
+    std::vector<float> planes(px * 3);
+    RT_HIP_CHECK(hipMemcpyAsync(planes.data(), c->fb.accum, px * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < px; i++) {
+        rgb[3 * i + 0] = planes[i];
+        rgb[3 * i + 1] = planes[px + i];
+        rgb[3 * i + 2] = planes[2 * px + i];
+    }
+    return RT_OK;
+}
+
+int rt_read_frame_f16(rt_context *c, uint16_t *rgba)
+{
+    if (!c || !rgba) return fail(RT_ERR_INVALID, "null argument");
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    size_t px = (size_t)c->width * c->height;
+    RT_HIP_CHECK(hipMemcpyAsync(rgba, c->fb.frame_f16, px * 4 * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_read_primary_ids(rt_context *c, int32_t *ids)
+{
+    if (!c || !ids) return fail(RT_ERR_INVALID, "null argument");
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    size_t px = (size_t)c->width * c->height;
+    RT_HIP_CHECK(hipMemcpyAsync(ids, c->fb.ids, px * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_set_counting(rt_context *c, int enable)
+{
+    if (!c) return fail(RT_ERR_INVALID, "null context");
+    c->counting = enable != 0;
+    return RT_OK;
+}
+
+int rt_read_counters(rt_context *c, uint64_t counters[8])
+{
+    if (!c || !counters) return fail(RT_ERR_INVALID, "null argument");
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    unsigned long long tmp[8];
+    RT_HIP_CHECK(hipMemcpyAsync(tmp, c->fb.counters, sizeof tmp, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 8; i++) counters[i] = tmp[i];
+    return RT_OK;
+}
+
+int rt_take_triangle_tests(rt_context *c, uint32_t *triangle_tests)
+{
+    if (!c || !triangle_tests) return fail(RT_ERR_INVALID, "null argument");
+    uint64_t cnt[8];
+    int rc = rt_read_counters(c, cnt);
+    if (rc) return rc;
+    uint64_t rays = cnt[0] - c->tests_taken_rays;
+    c->tests_taken_rays = cnt[0];
+    *triangle_tests = (uint32_t)(rays * (uint64_t)c->view.n_tris); // u32 wrap of raytracer_compute.wgsl:27
+    return RT_OK;
+}
+
+int rt_owned_rows(rt_context *c, int *rows)
+{
+    if (!c || !rows) return fail(RT_ERR_INVALID, "null argument");
+    *rows = c->local_rows;
+    return RT_OK;
+}
+
+int rt_export_owned_rows(rt_context *c, void *dst_device)
+{
+    if (!c || !dst_device) return fail(RT_ERR_INVALID, "null argument");
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    size_t n = (size_t)c->local_rows * c->width;
+    if (n == 0) return RT_OK;
+    hipLaunchKernelGGL(export_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->fb.accum,
+                       (float *)dst_device, c->width, c->height, c->local_rows, c->sm);
+    RT_HIP_CHECK(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_import_rows(rt_context *c, const void *src_device, int from_index)
+{
+    if (!c || !src_device) return fail(RT_ERR_INVALID, "null argument");
+    if (from_index < 0 || from_index >= c->sm.count) return fail(RT_ERR_INVALID, "from_index out of range");
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    StripeMap sm = c->sm;
+    sm.index = from_index;
+    int rows = owned_rows_of(c->height, sm);
+    size_t n = (size_t)rows * c->width;
+    if (n == 0) return RT_OK;
+    hipLaunchKernelGGL(import_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->fb.accum,
+                       (const float *)src_device, c->width, c->height, rows, sm);
+    RT_HIP_CHECK(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_scene_stats(rt_context *c, uint64_t out[4])
+{
+    if (!c || !out) return fail(RT_ERR_INVALID, "null argument");
+    if (!c->has_scene) return fail(RT_ERR_INVALID, "rt_set_scene has not been called");
+    out[0] = c->host_scene.nodes.size() / 4;
+    out[1] = c->host_scene.n_leaves;
+    out[2] = c->host_scene.max_depth;
+    out[3] = c->scene_bytes;
+    return RT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,362 @@
+// rt_scene.cpp -- host-side scene preparation (see rt_scene.h).
+// Built with -ffp-contract=off: the normals, areas, light powers and camera
+// basis computed here are the same single f32 operations the reference shader
+// performs per ray / per pixel, so that the kernels can read them instead of
+// recomputing them.
+#include "rt_scene.h"
+
+#include <algorithm>
+#include <cstring>
+#include <limits>
+
+namespace rt {
+
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset()
+    {
+        for (int a = 0; a < 3; a++) { lo[a] = std::numeric_limits<float>::infinity(); hi[a] = -lo[a]; }
+    }
+    void grow(const float p[3])
+    {
+        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); }
+    }
+    void grow(const Box &b)
+    {
+        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); }
+    }
+    float half_area() const
+    {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.0f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Prim {
+    Box box;
+    float centroid[3];
+    uint32_t index;
+};
+
+struct BuildNode {
+    Box box;
+    int32_t child[2]; // indices into the build-node vector, or -1 for a leaf
+    uint32_t first, count;
+};
+
+// The box of one triangle, widened so that any ray the Moeller-Trumbore test
+// accepts also meets the box: the test works in f32 and can accept rays that
+// pass a few 1e-5 outside the exact triangle; the margin is orders above that.
+Box padded_triangle_box(const float *rec)
+{
+    Box b;
+    b.reset();
+    b.grow(rec + 0);
+    b.grow(rec + 4);
+    b.grow(rec + 8);
+    float ext = std::max(b.hi[0] - b.lo[0], std::max(b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]));
+    float mag = 0.0f;
+    for (int a = 0; a < 3; a++) mag = std::max(mag, std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
+    float pad = 2e-4f + 1e-3f * ext + 4e-6f * mag;
+    for (int a = 0; a < 3; a++) { b.lo[a] -= pad; b.hi[a] += pad; }
+    return b;
+}
+
+class Builder {
+public:
+    Builder(std::vector<Prim> &prims, const BuildOptions &opt) : prims_(prims), opt_(opt) {}
+
+    int32_t build(uint32_t first, uint32_t count, uint32_t depth)
+    {
+        BuildNode node;
+        node.box.reset();
+        Box cbox;
+        cbox.reset();
+        for (uint32_t i = first; i < first + count; i++) {
+            node.box.grow(prims_[i].box);
+            cbox.grow(prims_[i].centroid);
+        }
+        node.child[0] = node.child[1] = -1;
+        node.first = first;
+        node.count = count;
+        int32_t self = (int32_t)nodes.size();
+        nodes.push_back(node);
+        max_depth = std::max(max_depth, depth);
+
+        if (count <= 1) return self;
+
+        // Depth budget: once only a balanced split can still end above the
+        // floor, split at the object median.
+        uint32_t levels_needed = 0;
+        while (((uint64_t)opt_.max_leaf << levels_needed) < count) levels_needed++;
+        bool force_median = depth + levels_needed >= opt_.max_depth;
+
+        uint32_t mid = 0;
+        bool split = false;
+        if (!force_median) split = sah_split(first, count, node.box, cbox, mid);
+        if (!split) {
+            if (count <= opt_.max_leaf) return self;
+            median_split(first, count, cbox, mid);
+        }
+        int32_t l = build(first, mid - first, depth + 1);
+        int32_t r = build(mid, first + count - mid, depth + 1);
+        nodes[self].child[0] = l;
+        nodes[self].child[1] = r;
+        return self;
+    }
+
+    std::vector<BuildNode> nodes;
+    uint32_t max_depth = 0;
+
+private:
+    static constexpr int kBins = 16;
+
+    bool sah_split(uint32_t first, uint32_t count, const Box &box, const Box &cbox, uint32_t &mid)
+    {
+        float best_cost = std::numeric_limits<float>::infinity();
+        int best_axis = -1, best_bin = -1;
+        float parent_area = box.half_area();
+        for (int axis = 0; axis < 3; axis++) {
+            float lo = cbox.lo[axis], ext = cbox.hi[axis] - lo;
+            if (!(ext > 0.0f)) continue;
+            Box bin_box[kBins];
+            uint32_t bin_n[kBins] = {0};
+            for (auto &b : bin_box) b.reset();
+            float k = (float)kBins / ext;
+            for (uint32_t i = first; i < first + count; i++) {
+                int b = std::min(kBins - 1, std::max(0, (int)((prims_[i].centroid[axis] - lo) * k)));
+                bin_n[b]++;
+                bin_box[b].grow(prims_[i].box);
+            }
+            float right_area[kBins];
+            uint32_t right_n[kBins];
+            Box acc;
+            acc.reset();
+            uint32_t n = 0;
+            for (int b = kBins - 1; b > 0; b--) {
+                acc.grow(bin_box[b]);
+                n += bin_n[b];
+                right_area[b] = acc.half_area();
+                right_n[b] = n;
+            }
+            acc.reset();
+            n = 0;
+            for (int b = 0; b < kBins - 1; b++) {
+                acc.grow(bin_box[b]);
+                n += bin_n[b];
+                if (n == 0 || right_n[b + 1] == 0) continue;
+                float cost = opt_.traversal_cost +
+                             opt_.triangle_cost * (acc.half_area() * (float)n + right_area[b + 1] * (float)right_n[b + 1]) /
+                                 std::max(parent_area, 1e-30f);
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+            }
+        }
+        if (best_axis < 0) return false;
+        float leaf_cost = opt_.triangle_cost * (float)count;
+        if (count <= opt_.max_leaf && leaf_cost <= best_cost) return false;
+        float lo = cbox.lo[best_axis], ext = cbox.hi[best_axis] - lo;
+        float k = (float)kBins / ext;
+        auto it = std::partition(prims_.begin() + first, prims_.begin() + first + count, [&](const Prim &p) {
+            int b = std::min(kBins - 1, std::max(0, (int)((p.centroid[best_axis] - lo) * k)));
+            return b <= best_bin;
+        });
+        mid = (uint32_t)(it - prims_.begin());
+        return mid > first && mid < first + count;
+    }
+
+    void median_split(uint32_t first, uint32_t count, const Box &cbox, uint32_t &mid)
+    {
+        int axis = 0;
+        float best = -1.0f;
+        for (int a = 0; a < 3; a++) {
+            float e = cbox.hi[a] - cbox.lo[a];
+            if (e > best) { best = e; axis = a; }
+        }
+        mid = first + count / 2;
+        std::nth_element(prims_.begin() + first, prims_.begin() + mid, prims_.begin() + first + count,
+                         [&](const Prim &a, const Prim &b) {
+                             if (a.centroid[axis] != b.centroid[axis]) return a.centroid[axis] < b.centroid[axis];
+                             return a.index < b.index;
+                         });
+    }
+
+    std::vector<Prim> &prims_;
+    const BuildOptions &opt_;
+};
+
+f3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
+
+int32_t leaf_link(uint32_t first, uint32_t count) { return (int32_t)~((first << 3) | (count - 1u)); }
+
+} // namespace
+
+void build_scene(const void *spheres, uint32_t n_spheres, const void *triangles, uint32_t n_tris,
+                 const BuildOptions &opt_in, BuiltScene &out)
+{
+    BuildOptions opt = opt_in;
+    opt.max_leaf = std::min(std::max(opt.max_leaf, 1u), 8u);
+    out = BuiltScene();
+    out.n_spheres = n_spheres;
+    out.n_tris = n_tris;
+
+    out.spheres.resize((size_t)n_spheres * 4);
+    if (n_spheres) std::memcpy(out.spheres.data(), spheres, (size_t)n_spheres * 64);
+    out.tri_raw.resize((size_t)n_tris * 6);
+    if (n_tris) std::memcpy(out.tri_raw.data(), triangles, (size_t)n_tris * 96);
+
+    const float *T = (const float *)out.tri_raw.data();
+
+    // Shading records, original order (fields: src/gpu-schemas.ts:29-38).
+    out.tri_shade.resize((size_t)n_tris * 3);
+    for (uint32_t i = 0; i < n_tris; i++) {
+        const float *r = T + (size_t)i * 24;
+        f3 v0 = ld3(r), v1 = ld3(r + 4), v2 = ld3(r + 8);
+        f3 e01 = sub(v1, v0), e02 = sub(v2, v0);
+        f3 n = normalize(cross(e01, e02)); // common.wgsl:202
+        f3 em = scale(ld3(r + 16), r[19]); // common.wgsl:209
+        out.tri_shade[3 * (size_t)i + 0] = mk4(n, r[20]);
+        out.tri_shade[3 * (size_t)i + 1] = mk4(ld3(r + 12), r[21]);
+        out.tri_shade[3 * (size_t)i + 2] = mk4(em, 0.0f);
+    }
+
+    // Emissive-triangle table: the two scans of raytracer_compute.wgsl:47-79.
+    float total_power = 0.0f;
+    uint32_t pass1 = 0;
+    for (uint32_t i = 0; i < n_tris; i++) {
+        const float *r = T + (size_t)i * 24;
+        if (r[19] <= 0.0f) continue;
+        f3 v0 = ld3(r), v1 = ld3(r + 4), v2 = ld3(r + 8);
+        float area = 0.5f * length(cross(sub(v1, v0), sub(v2, v0)));
+        float power = r[19] * area * luminance(ld3(r + 16));
+        total_power += power;
+        pass1++;
+    }
+    out.total_power = total_power;
+    out.n_lights_pass1 = pass1;
+    float acc = 0.0f;
+    auto push_light = [&](f3 v0, f3 v1, f3 v2, f3 em_color, float strength, bool accumulate) {
+        f3 e1 = sub(v1, v0), e2 = sub(v2, v0);
+        f3 c = cross(e1, e2);
+        float area = 0.5f * length(c);
+        float power = strength * area * luminance(em_color);
+        if (accumulate) acc += power;
+        f3 n = normalize(c); // raytracer_compute.wgsl:88-90
+        out.lights.push_back(mk4(v0, area));
+        out.lights.push_back(mk4(v1, power / total_power));
+        out.lights.push_back(mk4(v2, acc));
+        out.lights.push_back(mk4(n, 0.0f));
+        out.lights.push_back(mk4(scale(em_color, strength), 0.0f));
+    };
+    for (uint32_t i = 0; i < n_tris; i++) {
+        const float *r = T + (size_t)i * 24;
+        if (!(r[19] > 0.0f)) continue;
+        push_light(ld3(r), ld3(r + 4), ld3(r + 8), ld3(r + 16), r[19], true);
+        out.n_lights++;
+    }
+    // "var selected_triangle: Triangle;" left unassigned is the zero triangle.
+    push_light(mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), 0.0f, false);
+
+    // BVH over padded triangle boxes.
+    if (n_tris == 0) return;
+    std::vector<Prim> prims(n_tris);
+    for (uint32_t i = 0; i < n_tris; i++) {
+        const float *r = T + (size_t)i * 24;
+        prims[i].box = padded_triangle_box(r);
+        for (int a = 0; a < 3; a++) prims[i].centroid[a] = 0.5f * (prims[i].box.lo[a] + prims[i].box.hi[a]);
+        prims[i].index = i;
+    }
+    Builder b(prims, opt);
+    int32_t root = b.build(0, n_tris, 0);
+    out.max_depth = b.max_depth;
+
+    // Leaf-ordered intersection records.
+    out.tri_isect.resize((size_t)n_tris * 3);
+    for (uint32_t k = 0; k < n_tris; k++) {
+        const float *r = T + (size_t)prims[k].index * 24;
+        f3 v0 = ld3(r), v1 = ld3(r + 4), v2 = ld3(r + 8);
+        f3 e01 = sub(v1, v0), e02 = sub(v2, v0); // common.wgsl:172-173
+        out.tri_isect[3 * (size_t)k + 0] = mk4(v0, e01.x);
+        out.tri_isect[3 * (size_t)k + 1] = mk4(e01.y, e01.z, e02.x, e02.y);
+        out.tri_isect[3 * (size_t)k + 2] = mk4(e02.z, u2f(prims[k].index), 0.0f, 0.0f);
+    }
+
+    // Flatten: inner build nodes get consecutive indices in depth-first order.
+    const std::vector<BuildNode> &bn = b.nodes;
+    std::vector<int32_t> flat_index(bn.size(), -1);
+    int32_t n_inner = 0;
+    for (size_t i = 0; i < bn.size(); i++)
+        if (bn[i].child[0] >= 0) flat_index[i] = n_inner++;
+        else out.n_leaves++;
+    out.nodes.assign((size_t)n_inner * 4, mk4(0, 0, 0, 0));
+    auto link_of = [&](int32_t bi) -> int32_t {
+        return bn[bi].child[0] >= 0 ? flat_index[bi] : leaf_link(bn[bi].first, bn[bi].count);
+    };
+    for (size_t i = 0; i < bn.size(); i++) {
+        if (bn[i].child[0] < 0) continue;
+        const Box &b0 = bn[bn[i].child[0]].box, &b1 = bn[bn[i].child[1]].box;
+        f4 *n = &out.nodes[4 * (size_t)flat_index[i]];
+        n[0] = mk4(b0.lo[0], b0.lo[1], b0.lo[2], b0.hi[0]);
+        n[1] = mk4(b0.hi[1], b0.hi[2], b1.lo[0], b1.lo[1]);
+        n[2] = mk4(b1.lo[2], b1.hi[0], b1.hi[1], b1.hi[2]);
+        n[3] = mk4(u2f((uint32_t)link_of(bn[i].child[0])), u2f((uint32_t)link_of(bn[i].child[1])), 0.0f, 0.0f);
+    }
+    out.root = link_of(root);
+}
+
+bool make_frame_params(const void *uniforms80, uint32_t max_bounces, FrameParams &fp, std::string &err)
+{
+    const float *u = (const float *)uniforms80; // offsets: src/gpu-schemas.ts:3-17
+    f3 cam_position = ld3(u + 0), cam_rotation = ld3(u + 4);
+    float cam_fov = u[7], frameIndex = u[12], res_x = u[14], res_y = u[15], spp = u[16];
+    if (!(res_x >= 1.0f) || !(res_y >= 1.0f) || res_x > 65536.0f || res_y > 65536.0f) {
+        err = "uniforms.resolution out of range";
+        return false;
+    }
+    if (!(spp >= 1.0f) || spp > 65536.0f) {
+        err = "uniforms.samplesPerPixel must be in [1, 65536]";
+        return false;
+    }
+    if (!(frameIndex >= 0.0f) || frameIndex >= 4294967296.0f) {
+        err = "uniforms.frameIndex out of range";
+        return false;
+    }
+    // raytracer_compute.wgsl:303-316
+    f3 rotation_rad = divs(scale(cam_rotation, 3.14159f), 180.0f);
+    float yaw = rotation_rad.y, pitch = rotation_rad.x;
+    float cy, sy, cx, sx;
+    sincos_f(yaw, sy, cy);
+    sincos_f(pitch, sx, cx);
+    // common.wgsl:80-96 with v = (0, 0, -1)
+    f3 v = mk3(0.0f, 0.0f, -1.0f);
+    f3 r0 = mk3(cy, sy * sx, sy * cx);
+    f3 r1 = mk3(0.0f, cx, -sx);
+    f3 r2 = mk3(-sy, cy * sx, cy * cx);
+    f3 forward = normalize(mk3(dot(r0, v), dot(r1, v), dot(r2, v)));
+    f3 right = normalize(cross(forward, mk3(0.0f, 1.0f, 0.0f)));
+    f3 up = cross(right, forward);
+    float fov = cam_fov * 3.14159f / 180.0f;
+    float sh, ch;
+    sincos_f(fov * 0.5f, sh, ch);
+    fp.cam_pos = cam_position;
+    fp.right = right;
+    fp.up = up;
+    fp.forward = forward;
+    fp.focal_length = 1.0f / (sh / ch);
+    fp.aspect = res_x / res_y;
+    fp.res_x = res_x;
+    fp.res_y = res_y;
+    fp.spp_f = spp;
+    fp.frame_f = frameIndex;
+    fp.spp = (uint32_t)spp;
+    fp.seed_add = (uint32_t)frameIndex * 12345u;
+    fp.res_x_u = (uint32_t)res_x;
+    fp.max_bounces = max_bounces;
+    fp.width = (int32_t)res_x;
+    fp.height = (int32_t)res_y;
+    return true;
+}
+
+} // namespace rt

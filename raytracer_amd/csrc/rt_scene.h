@@ -1,0 +1,39 @@
+// rt_scene.h -- host-side scene preparation: reference byte layouts in,
+// device-ready tables (BVH nodes, leaf-ordered triangles, shading records,
+// emissive-triangle table) and per-frame constants out.
+#pragma once
+
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "rt_core.h"
+
+namespace rt {
+
+struct BuiltScene {
+    std::vector<f4> nodes, tri_isect, tri_shade, tri_raw, spheres, lights;
+    uint32_t n_spheres = 0, n_tris = 0, n_lights = 0, n_lights_pass1 = 0;
+    float total_power = 0.0f;
+    int32_t root = kNoRoot;
+    uint32_t n_leaves = 0, max_depth = 0;
+};
+
+struct BuildOptions {
+    uint32_t max_leaf = 4;    // triangles per leaf (<= 8)
+    uint32_t max_depth = 60;  // deepest leaf allowed (traversal stack bound)
+    float traversal_cost = 1.0f;
+    float triangle_cost = 1.2f;
+};
+
+// spheres: n_spheres records of 64 bytes; triangles: n_tris records of 96 bytes
+// (src/gpu-schemas.ts:19-38).
+void build_scene(const void *spheres, uint32_t n_spheres, const void *triangles, uint32_t n_tris,
+                 const BuildOptions &opt, BuiltScene &out);
+
+// Derives the per-frame constants from the 80-byte Uniforms blob
+// (src/gpu-schemas.ts:3-17) the way raytracer_compute.wgsl:283-316 does per pixel.
+// Returns false (with a message) if the blob cannot be rendered.
+bool make_frame_params(const void *uniforms80, uint32_t max_bounces, FrameParams &fp, std::string &err);
+
+} // namespace rt

@@ -1,0 +1,16 @@
+import sys, time
+sys.path.insert(0, '/root/repo')
+import numpy as np
+from raytracer_amd import capi, scene as S
+name, W, H, frames, spp = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+mode = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+sc = S.load_scene(S.scene_path(name))
+ctx = capi.Context(W, H)
+ctx.set_mode(mode)
+ctx.set_scene(S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles))
+ctx.set_uniforms(S.pack_uniforms(sc.camera, 1, W, H, spp))
+ctx.render_frames(1, 1); ctx.sync()
+c0 = ctx.read_counters()[0]
+t = time.time(); ctx.render_frames(2, frames); ctx.sync(); dt = time.time() - t
+c1 = ctx.read_counters()[0]
+print(name, W, H, frames, spp, 'mode', mode, 'ms/frame %.3f' % (dt * 1e3 / frames), 'gpu ms %.3f' % ctx.last_render_ms(), 'Mrays/s %.1f' % ((c1 - c0) / dt / 1e6), ctx.scene_stats())
