@@ -41,9 +41,18 @@ typedef enum rt_status {
 
 /* Traversal used by rt_render_frame. */
 typedef enum rt_mode {
-    RT_MODE_BVH = 0,        /* bounding-volume hierarchy traversal (default)          */
-    RT_MODE_BRUTE_FORCE = 1 /* every primitive per ray, the reference's own ray_all   */
+    RT_MODE_BVH = 0,         /* BVH traversal, persistent waves (default)                          */
+    RT_MODE_BRUTE_FORCE = 1, /* every primitive per ray, the reference's own ray_all, thread/pixel */
+    RT_MODE_BVH_TILES = 2    /* BVH traversal, one thread per pixel in the shader's loop nest      */
 } rt_mode;
+
+/* Scheduling knobs of the persistent kernel (rt_set_tuning); none changes the output. */
+typedef enum rt_tuning {
+    RT_TUNE_SHADE_NUM = 0,     /* shade finished lanes when traversing lanes * 8 < active lanes * value (0..8) */
+    RT_TUNE_LEAF_LANES = 1,    /* visit leaves once this many lanes of a wave wait at one (1..64)               */
+    RT_TUNE_BLOCKS_PER_CU = 2, /* resident 256-thread blocks per CU; 0 = occupancy query                        */
+    RT_TUNE_BATCH_FRAMES = 3   /* frames traced per launch by rt_render_frames (>= 1)                           */
+} rt_tuning;
 
 /* Message of the last failure on the calling thread ("" if none). */
 const char *rt_last_error(void);
@@ -93,8 +102,11 @@ int rt_set_uniforms(rt_context *ctx, const void *uniforms80);
  * default 6. */
 int rt_set_max_bounces(rt_context *ctx, uint32_t max_bounces);
 
-/* Select the traversal (default RT_MODE_BVH).  Both produce identical output. */
+/* Select the traversal (default RT_MODE_BVH).  All modes produce identical output. */
 int rt_set_mode(rt_context *ctx, int mode);
+
+/* Set one scheduling knob (rt_tuning).  No counterpart in the reference. */
+int rt_set_tuning(rt_context *ctx, int key, int value);
 
 /*
  * Render one frame with the current uniforms: the compute pass

@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_HERE, "librt_hip.so")
 
 RT_MODE_BVH = 0
 RT_MODE_BRUTE_FORCE = 1
+RT_MODE_BVH_TILES = 2
+RT_TUNE_SHADE_NUM, RT_TUNE_LEAF_LANES, RT_TUNE_BLOCKS_PER_CU, RT_TUNE_BATCH_FRAMES = 0, 1, 2, 3
 
 # name -> (restype, argtypes); must list every symbol include/rt_hip.h declares
 SYMBOLS = {
@@ -27,6 +29,7 @@ SYMBOLS = {
     "rt_set_max_bounces": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rt_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_set_counting": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rt_render_frame": (C.c_int, [C.c_void_p]),
     "rt_render_frames": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "rt_sync": (C.c_int, [C.c_void_p]),
@@ -114,6 +117,9 @@ class Context:
 
     def set_mode(self, mode: int):
         _check(self.lib.rt_set_mode(self.handle, mode))
+
+    def set_tuning(self, key: int, value: int):
+        _check(self.lib.rt_set_tuning(self.handle, key, value))
 
     def set_counting(self, enable: bool):
         _check(self.lib.rt_set_counting(self.handle, 1 if enable else 0))

@@ -10,6 +10,7 @@
 
 #include "../../include/rt_hip.h"
 #include "rt_core.h"
+#include "rt_lane.h"
 #include "rt_pixel.h"
 #include "rt_scene.h"
 
@@ -128,6 +129,187 @@ __global__ __launch_bounds__(kBlock) void render_tiles_kernel(rt::SceneView sc, 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Kernel B: persistent waves.  Every lane runs the path tracer as the state
+// machine of rt_lane.h and always owns one ray (closest-hit or shadow), so the
+// lanes of a wave need not be at the same sample, bounce or ray kind:
+//   - a wave takes work in 8x8-pixel tiles from a global counter (one atomic
+//     per 64 pixel-frames) into a wave-local pool; lanes that finish a pixel
+//     draw the next one from the pool through a ballot + prefix count;
+//   - traversal steps run while enough lanes are still traversing; when the
+//     share of traversing lanes drops below a threshold, the lanes whose ray is
+//     finished are shaded and given their next ray, then traversal resumes
+//     (suspended lanes keep their traversal stack in LDS);
+//   - leaf visits are postponed until enough lanes wait at a leaf.
+// Units are (frame, pixel) pairs of a batch of frames, frame-major.  With one
+// frame the finished pixel is accumulated in place (FUSED); with several the
+// frame colours go to a batch buffer and accumulate_batch_kernel applies the
+// recurrence in frame order.
+// ---------------------------------------------------------------------------
+struct SchedParams {
+    int shade_num;    // shade when traversing lanes * 8 < active lanes * shade_num
+    int leaf_lanes;   // visit leaves when at least this many lanes wait at one (or no lane is at an inner node)
+};
+
+struct BatchParams {
+    uint32_t first_frame; // frameIndex of batch frame 0
+    uint32_t n_frames;
+    uint2 *colors;        // [n_frames][local_rows * width] rgba16float bit patterns (unused when FUSED)
+};
+
+template <int STACK, bool COUNT, bool FUSED>
+__global__ __launch_bounds__(kBlock) void render_persistent_kernel(rt::SceneView sc, rt::FrameParams fp, StripeMap sm,
+                                                                    int local_rows, FrameBuffers fb, BatchParams bp,
+                                                                    unsigned int *work_counter, SchedParams sched)
+{
+    __shared__ int32_t lds_stack[STACK * kBlock];
+    const int lane = threadIdx.x & 63;
+    LdsStack<kBlock> stack;
+    stack.base = lds_stack + threadIdx.x;
+    stack.sp = 0;
+
+    const uint32_t tiles_x = (uint32_t)(fp.width + 7) / 8u, tiles_y = (uint32_t)(local_rows + 7) / 8u;
+    const uint32_t tiles_per_frame = tiles_x * tiles_y;
+    const uint32_t total_tiles = tiles_per_frame * bp.n_frames;
+
+    rt::Lane L;
+    L.mode = rt::kLaneNeedUnit;
+    uint32_t n_rays = 0;
+    rt::TestCounts cnt = {0, 0, 0, 0};
+    rt::TestCounts *cp = COUNT ? &cnt : nullptr;
+
+    uint32_t pool_tile = 0, pool_next = 64; // wave-uniform: current tile and next unused slot in it
+    bool exhausted = false;                 // wave-uniform: the global counter has run out
+
+    for (;;) {
+        // ---- hand out pixels to idle lanes ------------------------------------------------
+        for (;;) {
+            unsigned long long need = __ballot(L.mode == rt::kLaneNeedUnit);
+            if (need == 0ull) break;
+            if (pool_next >= 64u) {
+                if (exhausted) {
+                    if (L.mode == rt::kLaneNeedUnit) L.mode = rt::kLaneDead;
+                    break;
+                }
+                unsigned int tkt = 0;
+                if (lane == 0) tkt = atomicAdd(work_counter, 1u);
+                tkt = (unsigned int)__builtin_amdgcn_readfirstlane((int)tkt);
+                if (tkt >= total_tiles) { exhausted = true; continue; }
+                pool_tile = tkt;
+                pool_next = 0;
+            }
+            uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            uint32_t n_need = (uint32_t)__popcll(need);
+            if (L.mode == rt::kLaneNeedUnit && pool_next + rank < 64u) {
+                uint32_t slot = pool_next + rank;
+                uint32_t frame_k = pool_tile / tiles_per_frame, tile = pool_tile % tiles_per_frame;
+                int px = (int)((tile % tiles_x) * 8u + (slot & 7u));
+                int ly = (int)((tile / tiles_x) * 8u + (slot >> 3));
+                int py = stripe_global_row(sm, ly);
+                if (px < fp.width && ly < local_rows && py < fp.height) {
+                    L.px = px;
+                    L.py = py;
+                    L.frame_k = frame_k;
+                    if (fp.max_bounces == 0u) {
+                        // the bounce loop never runs: zero radiance, no rays (raytracer_compute.wgsl:196)
+                        rt::f3 zero = rt::divs(rt::mk3(0.0f, 0.0f, 0.0f), fp.spp_f);
+                        if (FUSED) store_pixel(fp, fb, px, py, zero, -1);
+                        else {
+                            size_t lp = (size_t)ly * fp.width + px;
+                            uint2 packed;
+                            packed.x = (uint32_t)rt::f32_to_f16_bits(zero.x) | ((uint32_t)rt::f32_to_f16_bits(zero.y) << 16);
+                            packed.y = (uint32_t)rt::f32_to_f16_bits(zero.z) | (0x3c00u << 16);
+                            bp.colors[(size_t)frame_k * ((size_t)local_rows * fp.width) + lp] = packed;
+                            if (frame_k + 1u == bp.n_frames) fb.ids[(size_t)py * fp.width + px] = -1;
+                        }
+                    } else {
+                        rt::FrameParams f = fp;
+                        if (!FUSED) f.seed_add = (uint32_t)(float)(bp.first_frame + frame_k) * 12345u;
+                        rt::lane_begin_pixel(sc, f, L, stack, n_rays, cp);
+                    }
+                }
+            }
+            pool_next += n_need < 64u - pool_next ? n_need : 64u - pool_next;
+        }
+        if (__ballot(L.mode != rt::kLaneDead) == 0ull) break;
+
+        // ---- traversal steps ----------------------------------------------------------------
+        for (;;) {
+            bool trav = L.mode == rt::kLaneTraverse;
+            int n_trav = __popcll(__ballot(trav));
+            if (n_trav == 0) break;
+            int n_shade = __popcll(__ballot(L.mode == rt::kLaneShade));
+            if (n_shade != 0 && n_trav * 8 < (n_trav + n_shade) * sched.shade_num) break;
+            bool inner = trav && rt::link_is_inner(L.cur);
+            if (inner) rt::lane_step_inner(sc, L, stack, cp);
+            bool leaf = L.mode == rt::kLaneTraverse && rt::link_is_leaf(L.cur);
+            int n_leaf = __popcll(__ballot(leaf));
+            if (n_leaf != 0) {
+                bool any_inner = __ballot(L.mode == rt::kLaneTraverse && rt::link_is_inner(L.cur)) != 0ull;
+                if (n_leaf >= sched.leaf_lanes || !any_inner) {
+                    if (leaf) rt::lane_step_leaf(sc, L, stack, cp);
+                }
+            }
+        }
+
+        // ---- shade the lanes whose ray is finished -----------------------------------------------
+        if (L.mode == rt::kLaneShade) {
+            rt::f3 color;
+            if (rt::lane_shade(sc, fp, L, stack, n_rays, color, cp)) {
+                if (FUSED) store_pixel(fp, fb, L.px, L.py, color, L.primary_id);
+                else {
+                    // local row of py: inverse of stripe_global_row
+                    int ly = (L.py / (sm.rows * sm.count)) * sm.rows + L.py % sm.rows;
+                    size_t lp = (size_t)ly * fp.width + L.px;
+                    uint2 packed;
+                    packed.x = (uint32_t)rt::f32_to_f16_bits(color.x) | ((uint32_t)rt::f32_to_f16_bits(color.y) << 16);
+                    packed.y = (uint32_t)rt::f32_to_f16_bits(color.z) | (0x3c00u << 16);
+                    bp.colors[(size_t)L.frame_k * ((size_t)local_rows * fp.width) + lp] = packed;
+                    if (L.frame_k + 1u == bp.n_frames) fb.ids[(size_t)L.py * fp.width + L.px] = L.primary_id;
+                }
+            }
+        }
+    }
+
+    uint32_t total = wave_sum(n_rays);
+    if (lane == 0 && total) atomicAdd(fb.counters, (unsigned long long)total);
+    if (COUNT) {
+        uint32_t b = wave_sum(cnt.boxes), t = wave_sum(cnt.tris), s = wave_sum(cnt.spheres), h = wave_sum(cnt.bounces);
+        if (lane == 0) {
+            atomicAdd(fb.counters + 1, (unsigned long long)b);
+            atomicAdd(fb.counters + 2, (unsigned long long)t);
+            atomicAdd(fb.counters + 3, (unsigned long long)s);
+            atomicAdd(fb.counters + 4, (unsigned long long)h);
+        }
+    }
+}
+
+// accumulator.wgsl:44-68 applied for the frames of a batch in order; also leaves
+// the last frame in the rgba16float intermediate buffer.
+__global__ void accumulate_batch_kernel(FrameBuffers fb, BatchParams bp, int width, int height, int local_rows, StripeMap sm)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t n = (size_t)local_rows * width;
+    if (i >= n) return;
+    int ly = (int)(i / width), x = (int)(i % width);
+    int y = stripe_global_row(sm, ly);
+    if (y >= height) return;
+    size_t p = (size_t)y * width + x, plane = (size_t)width * height;
+    float r = fb.accum[p], g = fb.accum[plane + p], b = fb.accum[2 * plane + p];
+    uint2 packed = make_uint2(0u, 0u);
+    for (uint32_t k = 0; k < bp.n_frames; k++) {
+        packed = bp.colors[(size_t)k * n + i];
+        float frame_f = (float)(bp.first_frame + k);
+        r = rt::accumulate_channel(r, rt::f16_bits_to_f32((uint16_t)(packed.x & 0xffffu)), frame_f);
+        g = rt::accumulate_channel(g, rt::f16_bits_to_f32((uint16_t)(packed.x >> 16)), frame_f);
+        b = rt::accumulate_channel(b, rt::f16_bits_to_f32((uint16_t)(packed.y & 0xffffu)), frame_f);
+    }
+    fb.accum[p] = r;
+    fb.accum[plane + p] = g;
+    fb.accum[2 * plane + p] = b;
+    reinterpret_cast<uint2 *>(fb.frame_f16)[p] = packed;
+}
+
 __global__ void fill_i32_kernel(int32_t *p, int32_t v, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -203,6 +385,14 @@ struct rt_context {
     bool counting = false;
     unsigned long long tests_taken_rays = 0; // rays already reported by rt_take_triangle_tests
 
+    // persistent-kernel launch state
+    int n_cus = 0;
+    unsigned int *d_work = nullptr; // kWorkCounters tile counters, one per launch
+    uint32_t work_used = 0;
+    uint2 *d_batch = nullptr;       // frame colours of a batch
+    size_t batch_capacity = 0;      // in frames
+    int tune_shade_num = 3, tune_leaf_lanes = 8, tune_blocks_per_cu = 0, tune_batch = 16;
+
     void free_scene()
     {
         for (rt::f4 *p : {d_nodes, d_tri_isect, d_tri_shade, d_tri_raw, d_spheres, d_lights}) (void)hipFree(p);
@@ -213,7 +403,10 @@ struct rt_context {
 
 namespace {
 
-int launch_frame(rt_context *c, const rt::FrameParams &fp)
+constexpr uint32_t kWorkCounters = 4096;
+constexpr size_t kBatchBytesCap = (size_t)1 << 30;
+
+int launch_tiles(rt_context *c, const rt::FrameParams &fp)
 {
     dim3 block(kBlock);
     dim3 grid((c->width + 31) / 32, (c->local_rows + 7) / 8);
@@ -235,6 +428,77 @@ int launch_frame(rt_context *c, const rt::FrameParams &fp)
     }
 #undef RT_LAUNCH_A
     RT_HIP_CHECK(hipGetLastError());
+    return RT_OK;
+}
+
+template <int STACK, bool COUNT, bool FUSED>
+int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchParams &bp, unsigned int *counter)
+{
+    auto kernel = render_persistent_kernel<STACK, COUNT, FUSED>;
+    int per_cu = c->tune_blocks_per_cu;
+    if (per_cu <= 0) {
+        RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
+        if (per_cu < 1) per_cu = 1;
+    }
+    uint64_t tiles = (uint64_t)((c->width + 7) / 8) * (uint64_t)((c->local_rows + 7) / 8) * bp.n_frames;
+    uint64_t blocks = std::min<uint64_t>((uint64_t)c->n_cus * per_cu, (tiles + 3) / 4);
+    if (blocks == 0) return RT_OK;
+    SchedParams sched{c->tune_shade_num, c->tune_leaf_lanes};
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, c->view, fp, c->sm, c->local_rows, c->fb,
+                       bp, counter, sched);
+    RT_HIP_CHECK(hipGetLastError());
+    return RT_OK;
+}
+
+template <bool COUNT, bool FUSED>
+int launch_persistent_d(rt_context *c, const rt::FrameParams &fp, const BatchParams &bp, unsigned int *counter)
+{
+    uint32_t depth = c->host_scene.max_depth;
+    if (depth < 16) return launch_persistent_t<16, COUNT, FUSED>(c, fp, bp, counter);
+    if (depth < 32) return launch_persistent_t<32, COUNT, FUSED>(c, fp, bp, counter);
+    return launch_persistent_t<64, COUNT, FUSED>(c, fp, bp, counter);
+}
+
+// Frames first .. first + n - 1 through the persistent kernel, in batches.
+int launch_persistent(rt_context *c, uint32_t first, uint32_t n)
+{
+    size_t local_px = (size_t)c->local_rows * c->width;
+    if (local_px == 0 || n == 0) return RT_OK;
+    uint64_t tiles_per_frame = (uint64_t)((c->width + 7) / 8) * (uint64_t)((c->local_rows + 7) / 8);
+    uint32_t max_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->tune_batch,
+                                                      std::min<uint64_t>(kBatchBytesCap / (local_px * sizeof(uint2)),
+                                                                         0x7fffffffull / tiles_per_frame)));
+    uint32_t done = 0;
+    while (done < n) {
+        uint32_t b = std::min(max_batch, n - done);
+        if (c->work_used == 0) RT_HIP_CHECK(hipMemsetAsync(c->d_work, 0, kWorkCounters * sizeof(unsigned int), c->stream));
+        unsigned int *counter = c->d_work + c->work_used;
+        c->work_used = (c->work_used + 1) % kWorkCounters;
+        c->uniforms[12] = (float)(first + done);
+        rt::FrameParams fp;
+        std::string err;
+        if (!rt::make_frame_params(c->uniforms, c->max_bounces, fp, err)) return fail(RT_ERR_INVALID, err);
+        BatchParams bp{first + done, b, nullptr};
+        int rc;
+        if (b == 1) {
+            rc = c->counting ? launch_persistent_d<true, true>(c, fp, bp, counter) : launch_persistent_d<false, true>(c, fp, bp, counter);
+            if (rc) return rc;
+        } else {
+            if (c->batch_capacity < b) {
+                if (c->d_batch) { RT_HIP_CHECK(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_batch); c->d_batch = nullptr; c->batch_capacity = 0; }
+                RT_HIP_CHECK(hipMalloc((void **)&c->d_batch, (size_t)max_batch * local_px * sizeof(uint2)));
+                c->batch_capacity = max_batch;
+            }
+            bp.colors = c->d_batch;
+            rc = c->counting ? launch_persistent_d<true, false>(c, fp, bp, counter) : launch_persistent_d<false, false>(c, fp, bp, counter);
+            if (rc) return rc;
+            hipLaunchKernelGGL(accumulate_batch_kernel, dim3((unsigned)((local_px + 255) / 256)), dim3(256), 0, c->stream, c->fb, bp,
+                               c->width, c->height, c->local_rows, c->sm);
+            RT_HIP_CHECK(hipGetLastError());
+        }
+        done += b;
+    }
+    c->uniforms[12] = (float)(first + n - 1);
     return RT_OK;
 }
 
@@ -288,6 +552,8 @@ int rt_create(int device, int width, int height, int stripe_rows, int stripe_ind
         (e = hipMalloc((void **)&c->fb.frame_f16, px * 4 * sizeof(uint16_t))) != hipSuccess ||
         (e = hipMalloc((void **)&c->fb.ids, px * sizeof(int32_t))) != hipSuccess ||
         (e = hipMalloc((void **)&c->fb.counters, 8 * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->d_work, kWorkCounters * sizeof(unsigned int))) != hipSuccess ||
+        (e = hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess ||
         (e = hipMemsetAsync(c->fb.accum, 0, px * 3 * sizeof(float), c->stream)) != hipSuccess ||
         (e = hipMemsetAsync(c->fb.frame_f16, 0, px * 4 * sizeof(uint16_t), c->stream)) != hipSuccess ||
         (e = hipMemsetAsync(c->fb.counters, 0, 8 * sizeof(unsigned long long), c->stream)) != hipSuccess) {
@@ -306,6 +572,7 @@ void rt_destroy(rt_context *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->free_scene();
+    (void)hipFree(c->d_work); (void)hipFree(c->d_batch);
     (void)hipFree(c->fb.accum); (void)hipFree(c->fb.frame_f16); (void)hipFree(c->fb.ids); (void)hipFree(c->fb.counters);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
@@ -366,8 +633,21 @@ int rt_set_max_bounces(rt_context *c, uint32_t max_bounces)
 int rt_set_mode(rt_context *c, int mode)
 {
     if (!c) return fail(RT_ERR_INVALID, "null context");
-    if (mode != RT_MODE_BVH && mode != RT_MODE_BRUTE_FORCE) return fail(RT_ERR_INVALID, "unknown mode");
+    if (mode != RT_MODE_BVH && mode != RT_MODE_BRUTE_FORCE && mode != RT_MODE_BVH_TILES) return fail(RT_ERR_INVALID, "unknown mode");
     c->mode = mode;
+    return RT_OK;
+}
+
+int rt_set_tuning(rt_context *c, int key, int value)
+{
+    if (!c) return fail(RT_ERR_INVALID, "null context");
+    switch (key) {
+    case RT_TUNE_SHADE_NUM: if (value < 0 || value > 8) return fail(RT_ERR_INVALID, "shade_num out of range"); c->tune_shade_num = value; break;
+    case RT_TUNE_LEAF_LANES: if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "leaf_lanes out of range"); c->tune_leaf_lanes = value; break;
+    case RT_TUNE_BLOCKS_PER_CU: if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "blocks_per_cu out of range"); c->tune_blocks_per_cu = value; break;
+    case RT_TUNE_BATCH_FRAMES: if (value < 1 || value > 4096) return fail(RT_ERR_INVALID, "batch_frames out of range"); c->tune_batch = value; break;
+    default: return fail(RT_ERR_INVALID, "unknown tuning key");
+    }
     return RT_OK;
 }
 
@@ -377,12 +657,16 @@ int rt_render_frames(rt_context *c, uint32_t first_frame_index, uint32_t n_frame
     if (rc) return rc;
     RT_HIP_CHECK(hipSetDevice(c->device));
     RT_HIP_CHECK(hipEventRecord(c->ev_start, c->stream));
-    for (uint32_t k = 0; k < n_frames; k++) {
-        c->uniforms[12] = (float)(first_frame_index + k);
-        rt::FrameParams fp;
-        std::string err;
-        if (!rt::make_frame_params(c->uniforms, c->max_bounces, fp, err)) return fail(RT_ERR_INVALID, err);
-        if ((rc = launch_frame(c, fp))) return rc;
+    if (c->mode == RT_MODE_BVH) {
+        if ((rc = launch_persistent(c, first_frame_index, n_frames))) return rc;
+    } else {
+        for (uint32_t k = 0; k < n_frames; k++) {
+            c->uniforms[12] = (float)(first_frame_index + k);
+            rt::FrameParams fp;
+            std::string err;
+            if (!rt::make_frame_params(c->uniforms, c->max_bounces, fp, err)) return fail(RT_ERR_INVALID, err);
+            if ((rc = launch_tiles(c, fp))) return rc;
+        }
     }
     RT_HIP_CHECK(hipEventRecord(c->ev_stop, c->stream));
     c->timed = true;

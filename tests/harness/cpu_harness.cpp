@@ -141,3 +141,122 @@ extern "C" int har_debug_pixel(const void *uniforms80, const void *spheres, uint
     }
     return mismatches;
 }
+
+// ---------------------------------------------------------------------------
+// Emulation of the persistent kernel's wave: 64 rt::Lane state machines driven
+// by the same phases (hand out pixels, traversal steps with a shading
+// threshold and postponed leaves, shade).  Checks rt_lane.h on the host.
+// ---------------------------------------------------------------------------
+#include "../../raytracer_amd/csrc/rt_lane.h"
+
+extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spheres, uint32_t n_spheres,
+                                       const void *tris, uint32_t n_tris, uint32_t max_bounces,
+                                       uint32_t first_frame, uint32_t n_frames, int shade_num, int leaf_lanes,
+                                       float *accum, uint16_t *frame_f16, int32_t *ids, uint64_t *counters,
+                                       int n_threads)
+{
+    rt::BuiltScene bs;
+    rt::BuildOptions opt;
+    rt::build_scene(spheres, n_spheres, tris, n_tris, opt, bs);
+    float uni[20];
+    std::memcpy(uni, uniforms80, 80);
+    uni[12] = (float)first_frame;
+    rt::FrameParams fp;
+    std::string err;
+    if (!rt::make_frame_params(uni, max_bounces, fp, err)) return -1;
+    rt::SceneView sc;
+    sc.nodes = bs.nodes.data(); sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data();
+    sc.tri_raw = bs.tri_raw.data(); sc.spheres = bs.spheres.data(); sc.lights = bs.lights.data();
+    sc.n_spheres = bs.n_spheres; sc.n_tris = bs.n_tris; sc.n_lights = bs.n_lights;
+    sc.n_lights_pass1 = bs.n_lights_pass1; sc.total_power = bs.total_power; sc.root = bs.root;
+
+    const int W = fp.width, H = fp.height;
+    const uint32_t tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8, tiles_per_frame = tiles_x * tiles_y;
+    const uint32_t total_tiles = tiles_per_frame * n_frames;
+    std::vector<uint16_t> batch((size_t)n_frames * W * H * 4);
+    std::atomic<uint32_t> work{0};
+    std::atomic<uint64_t> rays{0};
+
+    auto wave = [&]() {
+        rt::Lane L[64];
+        HostStack st[64];
+        for (auto &l : L) l.mode = rt::kLaneNeedUnit;
+        uint32_t n_rays = 0, pool_tile = 0, pool_next = 64;
+        bool exhausted = false;
+        for (;;) {
+            for (;;) {
+                int n_need = 0;
+                for (auto &l : L) n_need += l.mode == rt::kLaneNeedUnit;
+                if (!n_need) break;
+                if (pool_next >= 64) {
+                    if (exhausted) { for (auto &l : L) if (l.mode == rt::kLaneNeedUnit) l.mode = rt::kLaneDead; break; }
+                    uint32_t tkt = work.fetch_add(1);
+                    if (tkt >= total_tiles) { exhausted = true; continue; }
+                    pool_tile = tkt; pool_next = 0;
+                }
+                uint32_t rank = 0;
+                for (int i = 0; i < 64; i++) {
+                    if (L[i].mode != rt::kLaneNeedUnit) continue;
+                    uint32_t slot = pool_next + rank++;
+                    if (slot >= 64) continue;
+                    uint32_t frame_k = pool_tile / tiles_per_frame, tile = pool_tile % tiles_per_frame;
+                    int px = (tile % tiles_x) * 8 + (slot & 7), py = (tile / tiles_x) * 8 + (slot >> 3);
+                    if (px < W && py < H) {
+                        L[i].px = px; L[i].py = py; L[i].frame_k = frame_k;
+                        rt::FrameParams f = fp;
+                        f.seed_add = (uint32_t)(float)(first_frame + frame_k) * 12345u;
+                        rt::lane_begin_pixel(sc, f, L[i], st[i], n_rays, nullptr);
+                    }
+                }
+                pool_next += std::min<uint32_t>(n_need, 64 - pool_next);
+            }
+            bool any_alive = false;
+            for (auto &l : L) any_alive |= l.mode != rt::kLaneDead;
+            if (!any_alive) break;
+            for (;;) {
+                int n_trav = 0, n_shade = 0;
+                for (auto &l : L) { n_trav += l.mode == rt::kLaneTraverse; n_shade += l.mode == rt::kLaneShade; }
+                if (!n_trav) break;
+                if (n_shade && n_trav * 8 < (n_trav + n_shade) * shade_num) break;
+                for (int i = 0; i < 64; i++)
+                    if (L[i].mode == rt::kLaneTraverse && rt::link_is_inner(L[i].cur)) rt::lane_step_inner(sc, L[i], st[i], nullptr);
+                int n_leaf = 0, n_inner = 0;
+                for (auto &l : L) {
+                    n_leaf += l.mode == rt::kLaneTraverse && rt::link_is_leaf(l.cur);
+                    n_inner += l.mode == rt::kLaneTraverse && rt::link_is_inner(l.cur);
+                }
+                if (n_leaf && (n_leaf >= leaf_lanes || !n_inner))
+                    for (int i = 0; i < 64; i++)
+                        if (L[i].mode == rt::kLaneTraverse && rt::link_is_leaf(L[i].cur)) rt::lane_step_leaf(sc, L[i], st[i], nullptr);
+            }
+            for (int i = 0; i < 64; i++) {
+                if (L[i].mode != rt::kLaneShade) continue;
+                rt::f3 c;
+                if (rt::lane_shade(sc, fp, L[i], st[i], n_rays, c, nullptr)) {
+                    size_t p = (size_t)L[i].py * W + L[i].px;
+                    uint16_t *dst = &batch[((size_t)L[i].frame_k * W * H + p) * 4];
+                    dst[0] = rt::f32_to_f16_bits(c.x); dst[1] = rt::f32_to_f16_bits(c.y);
+                    dst[2] = rt::f32_to_f16_bits(c.z); dst[3] = 0x3c00;
+                    if (L[i].frame_k + 1 == n_frames && ids) ids[p] = L[i].primary_id;
+                }
+            }
+        }
+        rays += n_rays;
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < n_threads; i++) th.emplace_back(wave);
+    wave();
+    for (auto &t : th) t.join();
+    size_t plane = (size_t)W * H;
+    for (size_t p = 0; p < plane; p++) {
+        for (uint32_t k = 0; k < n_frames; k++) {
+            const uint16_t *src = &batch[((size_t)k * plane + p) * 4];
+            float ff = (float)(first_frame + k);
+            for (int ch = 0; ch < 3; ch++)
+                accum[ch * plane + p] = rt::accumulate_channel(accum[ch * plane + p], rt::f16_bits_to_f32(src[ch]), ff);
+            if (k + 1 == n_frames && frame_f16) std::memcpy(frame_f16 + 4 * p, src, 8);
+        }
+    }
+    if (counters) counters[0] += rays;
+    return 0;
+}

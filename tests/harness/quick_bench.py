@@ -7,10 +7,13 @@ mode = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 sc = S.load_scene(S.scene_path(name))
 ctx = capi.Context(W, H)
 ctx.set_mode(mode)
+import os
+for k, name_ in enumerate(['SHADE', 'LEAF', 'BPC', 'BATCH']):
+    if 'RT_' + name_ in os.environ: ctx.set_tuning(k, int(os.environ['RT_' + name_]))
 ctx.set_scene(S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles))
 ctx.set_uniforms(S.pack_uniforms(sc.camera, 1, W, H, spp))
 ctx.render_frames(1, 1); ctx.sync()
 c0 = ctx.read_counters()[0]
 t = time.time(); ctx.render_frames(2, frames); ctx.sync(); dt = time.time() - t
 c1 = ctx.read_counters()[0]
-print(name, W, H, frames, spp, 'mode', mode, 'ms/frame %.3f' % (dt * 1e3 / frames), 'gpu ms %.3f' % ctx.last_render_ms(), 'Mrays/s %.1f' % ((c1 - c0) / dt / 1e6), ctx.scene_stats())
+print(name, W, H, frames, spp, 'mode', mode, {k: v for k, v in os.environ.items() if k.startswith('RT_')}, 'ms/frame %.3f' % (dt * 1e3 / frames), 'gpu ms %.3f' % ctx.last_render_ms(), 'Mrays/s %.1f' % ((c1 - c0) / dt / 1e6), ctx.scene_stats())

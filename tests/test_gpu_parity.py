@@ -41,7 +41,7 @@ def run_pair(scene, width, height, frames, spp, mode, max_bounces=6):
     ctx.close()
 
 
-@pytest.mark.parametrize("mode", [capi.RT_MODE_BRUTE_FORCE, capi.RT_MODE_BVH])
+@pytest.mark.parametrize("mode", [capi.RT_MODE_BRUTE_FORCE, capi.RT_MODE_BVH_TILES, capi.RT_MODE_BVH])
 @pytest.mark.parametrize("name,width,height,frames,spp", [
     ("spheres", 64, 36, 2, 16),
     ("spheres", 160, 90, 4, 1),
@@ -59,3 +59,48 @@ def test_config_a_spheres_640x360_16spp(scenes):
 
 def test_max_bounces_8(scenes):
     run_pair(scenes["boxes"], 96, 54, 2, 4, capi.RT_MODE_BVH, max_bounces=8)
+
+
+def run_batched(scene, width, height, frames, spp, batch, tuning=(), stripes=None):
+    """rt_render_frames (several frames per launch + ordered accumulate) against the oracle."""
+    orc = O.OracleRenderer(scene, width, height)
+    orc.set_samples_per_pixel(spp)
+    orc.render_frames(frames)
+    ctx = capi.Context(width, height)
+    ctx.set_scene(S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles))
+    ctx.set_tuning(capi.RT_TUNE_BATCH_FRAMES, batch)
+    for key, value in tuning:
+        ctx.set_tuning(key, value)
+    ctx.set_uniforms(S.pack_uniforms(scene.camera, 1, width, height, spp))
+    ctx.render_frames(1, frames)
+    assert np.array_equal(ctx.read_primary_ids(), orc.ids)
+    assert _f16_equal(ctx.read_frame_f16(), orc.frame_f16)
+    assert np.array_equal(ctx.read_accum(), orc.accum_rgb())
+    assert int(ctx.read_counters()[0]) == int(orc.counters[0])
+    ctx.close()
+
+
+@pytest.mark.parametrize("batch", [1, 2, 3, 16])
+def test_batched_frames_bit_exact(scenes, batch):
+    run_batched(scenes["suzanne"], 100, 61, 5, 2, batch)
+
+
+@pytest.mark.parametrize("tuning", [
+    ((capi.RT_TUNE_SHADE_NUM, 0), (capi.RT_TUNE_LEAF_LANES, 1)),
+    ((capi.RT_TUNE_SHADE_NUM, 8), (capi.RT_TUNE_LEAF_LANES, 64)),
+    ((capi.RT_TUNE_BLOCKS_PER_CU, 1),),
+])
+def test_scheduling_knobs_do_not_change_output(scenes, tuning):
+    run_batched(scenes["boxes"], 96, 54, 3, 4, 2, tuning)
+
+
+def test_triangle_test_counter_wraps_like_u32(scenes):
+    scene = scenes["suzanne"]
+    ctx = capi.Context(64, 36)
+    ctx.set_scene(S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles))
+    ctx.set_uniforms(S.pack_uniforms(scene.camera, 1, 64, 36, 16))
+    ctx.render_frame()
+    rays = int(ctx.read_counters()[0])
+    assert ctx.take_triangle_tests() == (rays * 982) % 2**32
+    assert ctx.take_triangle_tests() == 0
+    ctx.close()
