@@ -51,7 +51,8 @@ typedef enum rt_tuning {
     RT_TUNE_SHADE_NUM = 0,     /* shade finished lanes when traversing lanes * 8 < active lanes * value (0..8) */
     RT_TUNE_LEAF_LANES = 1,    /* visit leaves once this many lanes of a wave wait at one (1..64)               */
     RT_TUNE_BLOCKS_PER_CU = 2, /* resident 256-thread blocks per CU; 0 = occupancy query                        */
-    RT_TUNE_BATCH_FRAMES = 3   /* frames traced per launch by rt_render_frames (>= 1)                           */
+    RT_TUNE_BATCH_FRAMES = 3,  /* frames traced per launch by rt_render_frames (>= 1)                           */
+    RT_TUNE_SHADOW_DONE_LANES = 4 /* finish shadow rays once this many lanes of a wave wait for it (1..64)      */
 } rt_tuning;
 
 /* Message of the last failure on the calling thread ("" if none). */
@@ -158,12 +159,15 @@ int rt_read_primary_ids(rt_context *ctx, int32_t *ids);
  *   [0] rays traced (calls of the reference's ray_all: closest-hit + shadow)
  *   [1] node visits (each tests the two child boxes of one node)
  *   [2] triangle tests   [3] sphere tests   [4] bounces (shaded hits)
- *   [5..7] reserved, 0
- * [1..4] advance only while counting is enabled (rt_set_counting), which
+ *   persistent kernel only, per wave: [5] inner-step iterations, [6] lanes active
+ *   in them, [7] leaf-step iterations, [8] lanes active in them, [9] shade
+ *   passes, [10] lanes active in them, [11] shadow hand-over steps, [12] lanes
+ *   active in them; [13..15] reserved, 0
+ * [1..12] advance only while counting is enabled (rt_set_counting), which
  * selects an instrumented build of the same kernel; timings are taken with
  * counting off.  [0] always advances.
  */
-int rt_read_counters(rt_context *ctx, uint64_t counters[8]);
+int rt_read_counters(rt_context *ctx, uint64_t counters[16]);
 int rt_set_counting(rt_context *ctx, int enable);
 
 /*

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "librt_hip.so")
 RT_MODE_BVH = 0
 RT_MODE_BRUTE_FORCE = 1
 RT_MODE_BVH_TILES = 2
-RT_TUNE_SHADE_NUM, RT_TUNE_LEAF_LANES, RT_TUNE_BLOCKS_PER_CU, RT_TUNE_BATCH_FRAMES = 0, 1, 2, 3
+RT_TUNE_SHADE_NUM, RT_TUNE_LEAF_LANES, RT_TUNE_BLOCKS_PER_CU, RT_TUNE_BATCH_FRAMES, RT_TUNE_SHADOW_DONE_LANES = 0, 1, 2, 3, 4
 
 # name -> (restype, argtypes); must list every symbol include/rt_hip.h declares
 SYMBOLS = {
@@ -154,7 +154,7 @@ class Context:
         return out
 
     def read_counters(self) -> np.ndarray:
-        out = np.zeros(8, dtype=np.uint64)
+        out = np.zeros(16, dtype=np.uint64)
         _check(self.lib.rt_read_counters(self.handle, _ptr(out)))
         return out
 

@@ -530,18 +530,23 @@ RT_HD f3 nee_contribution(const LightSample &ts, f3 hit_normal, float cos_theta,
     return divs(c, ts.pdf);
 }
 
-// Everything of one bounce after the shadow test (raytracer_compute.wgsl:229-274).
-// Returns false when the path ends; otherwise ro/rd hold the next ray.
-RT_HD bool finish_bounce(const Hit &hit, uint32_t bounce, f3 &ro, f3 &rd, f3 &color, f3 &light,
+// Everything of one bounce after the shadow test (raytracer_compute.wgsl:229-274)
+// except the addition to `light`: the emission term of :242 is returned in em
+// (has_em says whether the shader adds it) so that the caller can add it after
+// the light-sample term of :223, in the shader's order.  Returns false when the
+// path ends; otherwise ro/rd hold the next ray.
+RT_HD bool finish_bounce(const Hit &hit, uint32_t bounce, f3 &ro, f3 &rd, f3 &color, f3 &em, bool &has_em,
                          bool &is_specular_bounce, uint32_t &state)
 {
     bool is_primary_ray = (bounce == 0u);
     bool is_emissive = (hit.emission.x + hit.emission.y + hit.emission.z) > 0.01f;
-    if ((is_primary_ray && is_emissive) || is_specular_bounce) {
+    has_em = (is_primary_ray && is_emissive) || is_specular_bounce;
+    em = mk3(0.0f, 0.0f, 0.0f);
+    if (has_em) {
         f3 incoming_dir = neg(normalize(rd));
         float brdf_pdf_val = brdf_pdf(hit.normal, incoming_dir);
         float mis_weight = power_heuristic(brdf_pdf_val, 0.001f);
-        light = add(light, scale(mul(hit.emission, color), mis_weight));
+        em = scale(mul(hit.emission, color), mis_weight);
     }
 
     color = mul(color, hit.color);

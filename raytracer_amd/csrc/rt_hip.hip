@@ -140,7 +140,8 @@ __global__ __launch_bounds__(kBlock) void render_tiles_kernel(rt::SceneView sc, 
 //     share of traversing lanes drops below a threshold, the lanes whose ray is
 //     finished are shaded and given their next ray, then traversal resumes
 //     (suspended lanes keep their traversal stack in LDS);
-//   - leaf visits are postponed until enough lanes wait at a leaf.
+//   - triangle tests and the hand-over after a finished shadow ray are postponed
+//     until enough lanes wait for them.
 // Units are (frame, pixel) pairs of a batch of frames, frame-major.  With one
 // frame the finished pixel is accumulated in place (FUSED); with several the
 // frame colours go to a batch buffer and accumulate_batch_kernel applies the
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(kBlock) void render_tiles_kernel(rt::SceneView sc, 
 struct SchedParams {
     int shade_num;    // shade when traversing lanes * 8 < active lanes * shade_num
     int leaf_lanes;   // visit leaves when at least this many lanes wait at one (or no lane is at an inner node)
+    int sdone_lanes;  // finish shadow rays when at least this many lanes wait for it (or no lane is traversing)
 };
 
 struct BatchParams {
@@ -178,10 +180,29 @@ __global__ __launch_bounds__(kBlock) void render_persistent_kernel(rt::SceneView
     rt::TestCounts cnt = {0, 0, 0, 0};
     rt::TestCounts *cp = COUNT ? &cnt : nullptr;
 
+    uint32_t ph_inner_it = 0, ph_inner_ln = 0, ph_leaf_it = 0, ph_leaf_ln = 0, ph_shade_it = 0, ph_shade_ln = 0,
+             ph_sdone_it = 0, ph_sdone_ln = 0; // COUNT only
     uint32_t pool_tile = 0, pool_next = 64; // wave-uniform: current tile and next unused slot in it
     bool exhausted = false;                 // wave-uniform: the global counter has run out
 
     for (;;) {
+        // ---- store finished pixels -----------------------------------------------------------
+        if (L.mode == rt::kLanePixelDone) {
+            rt::f3 color = rt::lane_pixel_color(fp, L);
+            if (FUSED) store_pixel(fp, fb, L.px, L.py, color, L.primary_id);
+            else {
+                // local row of py: inverse of stripe_global_row
+                int ly = (L.py / (sm.rows * sm.count)) * sm.rows + L.py % sm.rows;
+                size_t lp = (size_t)ly * fp.width + L.px;
+                uint2 packed;
+                packed.x = (uint32_t)rt::f32_to_f16_bits(color.x) | ((uint32_t)rt::f32_to_f16_bits(color.y) << 16);
+                packed.y = (uint32_t)rt::f32_to_f16_bits(color.z) | (0x3c00u << 16);
+                bp.colors[(size_t)L.frame_k * ((size_t)local_rows * fp.width) + lp] = packed;
+                if (L.frame_k + 1u == bp.n_frames) fb.ids[(size_t)L.py * fp.width + L.px] = L.primary_id;
+            }
+            L.mode = rt::kLaneNeedUnit;
+        }
+
         // ---- hand out pixels to idle lanes ------------------------------------------------
         for (;;) {
             unsigned long long need = __ballot(L.mode == rt::kLaneNeedUnit);
@@ -212,16 +233,9 @@ __global__ __launch_bounds__(kBlock) void render_persistent_kernel(rt::SceneView
                     L.frame_k = frame_k;
                     if (fp.max_bounces == 0u) {
                         // the bounce loop never runs: zero radiance, no rays (raytracer_compute.wgsl:196)
-                        rt::f3 zero = rt::divs(rt::mk3(0.0f, 0.0f, 0.0f), fp.spp_f);
-                        if (FUSED) store_pixel(fp, fb, px, py, zero, -1);
-                        else {
-                            size_t lp = (size_t)ly * fp.width + px;
-                            uint2 packed;
-                            packed.x = (uint32_t)rt::f32_to_f16_bits(zero.x) | ((uint32_t)rt::f32_to_f16_bits(zero.y) << 16);
-                            packed.y = (uint32_t)rt::f32_to_f16_bits(zero.z) | (0x3c00u << 16);
-                            bp.colors[(size_t)frame_k * ((size_t)local_rows * fp.width) + lp] = packed;
-                            if (frame_k + 1u == bp.n_frames) fb.ids[(size_t)py * fp.width + px] = -1;
-                        }
+                        L.total = rt::mk3(0.0f, 0.0f, 0.0f);
+                        L.primary_id = -1;
+                        L.mode = rt::kLanePixelDone;
                     } else {
                         rt::FrameParams f = fp;
                         if (!FUSED) f.seed_add = (uint32_t)(float)(bp.first_frame + frame_k) * 12345u;
@@ -235,40 +249,36 @@ __global__ __launch_bounds__(kBlock) void render_persistent_kernel(rt::SceneView
 
         // ---- traversal steps ----------------------------------------------------------------
         for (;;) {
-            bool trav = L.mode == rt::kLaneTraverse;
-            int n_trav = __popcll(__ballot(trav));
-            if (n_trav == 0) break;
-            int n_shade = __popcll(__ballot(L.mode == rt::kLaneShade));
-            if (n_shade != 0 && n_trav * 8 < (n_trav + n_shade) * sched.shade_num) break;
-            bool inner = trav && rt::link_is_inner(L.cur);
+            int n_trav = __popcll(__ballot(L.mode == rt::kLaneTraverse));
+            int n_sdone = __popcll(__ballot(L.mode == rt::kLaneShadowDone));
+            if (n_trav + n_sdone == 0) break;
+            int n_ready = __popcll(__ballot(L.mode == rt::kLaneShadeClosest || L.mode == rt::kLanePixelDone));
+            if (n_ready != 0 && (n_trav + n_sdone) * 8 < (n_trav + n_sdone + n_ready) * sched.shade_num) break;
+
+            bool inner = L.mode == rt::kLaneTraverse && rt::link_is_inner(L.cur);
+            if (COUNT) { int n_in = __popcll(__ballot(inner)); if (n_in) { ph_inner_it++; ph_inner_ln += n_in; } }
             if (inner) rt::lane_step_inner(sc, L, stack, cp);
+
             bool leaf = L.mode == rt::kLaneTraverse && rt::link_is_leaf(L.cur);
             int n_leaf = __popcll(__ballot(leaf));
-            if (n_leaf != 0) {
-                bool any_inner = __ballot(L.mode == rt::kLaneTraverse && rt::link_is_inner(L.cur)) != 0ull;
-                if (n_leaf >= sched.leaf_lanes || !any_inner) {
-                    if (leaf) rt::lane_step_leaf(sc, L, stack, cp);
-                }
+            bool any_inner = __ballot(L.mode == rt::kLaneTraverse && rt::link_is_inner(L.cur)) != 0ull;
+            if (n_leaf != 0 && (n_leaf >= sched.leaf_lanes || !any_inner)) {
+                if (COUNT) { ph_leaf_it++; ph_leaf_ln += n_leaf; }
+                if (leaf) rt::lane_step_triangle(sc, L, stack, cp);
+            }
+
+            // shadow rays that have finished: add their light, start the parked ray
+            bool sdone = L.mode == rt::kLaneShadowDone;
+            n_sdone = __popcll(__ballot(sdone));
+            if (n_sdone != 0 && (n_sdone >= sched.sdone_lanes || __ballot(L.mode == rt::kLaneTraverse) == 0ull)) {
+                if (COUNT) { ph_sdone_it++; ph_sdone_ln += n_sdone; }
+                if (sdone) rt::lane_shadow_done(sc, fp, L, stack, n_rays, cp);
             }
         }
 
-        // ---- shade the lanes whose ray is finished -----------------------------------------------
-        if (L.mode == rt::kLaneShade) {
-            rt::f3 color;
-            if (rt::lane_shade(sc, fp, L, stack, n_rays, color, cp)) {
-                if (FUSED) store_pixel(fp, fb, L.px, L.py, color, L.primary_id);
-                else {
-                    // local row of py: inverse of stripe_global_row
-                    int ly = (L.py / (sm.rows * sm.count)) * sm.rows + L.py % sm.rows;
-                    size_t lp = (size_t)ly * fp.width + L.px;
-                    uint2 packed;
-                    packed.x = (uint32_t)rt::f32_to_f16_bits(color.x) | ((uint32_t)rt::f32_to_f16_bits(color.y) << 16);
-                    packed.y = (uint32_t)rt::f32_to_f16_bits(color.z) | (0x3c00u << 16);
-                    bp.colors[(size_t)L.frame_k * ((size_t)local_rows * fp.width) + lp] = packed;
-                    if (L.frame_k + 1u == bp.n_frames) fb.ids[(size_t)L.py * fp.width + L.px] = L.primary_id;
-                }
-            }
-        }
+        // ---- shade the lanes whose closest-hit ray is finished ------------------------------------
+        if (COUNT) { int n_sh = __popcll(__ballot(L.mode == rt::kLaneShadeClosest)); if (n_sh) { ph_shade_it++; ph_shade_ln += n_sh; } }
+        if (L.mode == rt::kLaneShadeClosest) rt::lane_shade_closest(sc, fp, L, stack, n_rays, cp);
     }
 
     uint32_t total = wave_sum(n_rays);
@@ -280,6 +290,14 @@ __global__ __launch_bounds__(kBlock) void render_persistent_kernel(rt::SceneView
             atomicAdd(fb.counters + 2, (unsigned long long)t);
             atomicAdd(fb.counters + 3, (unsigned long long)s);
             atomicAdd(fb.counters + 4, (unsigned long long)h);
+            atomicAdd(fb.counters + 5, (unsigned long long)ph_inner_it);
+            atomicAdd(fb.counters + 6, (unsigned long long)ph_inner_ln);
+            atomicAdd(fb.counters + 7, (unsigned long long)ph_leaf_it);
+            atomicAdd(fb.counters + 8, (unsigned long long)ph_leaf_ln);
+            atomicAdd(fb.counters + 9, (unsigned long long)ph_shade_it);
+            atomicAdd(fb.counters + 10, (unsigned long long)ph_shade_ln);
+            atomicAdd(fb.counters + 11, (unsigned long long)ph_sdone_it);
+            atomicAdd(fb.counters + 12, (unsigned long long)ph_sdone_ln);
         }
     }
 }
@@ -391,7 +409,7 @@ struct rt_context {
     uint32_t work_used = 0;
     uint2 *d_batch = nullptr;       // frame colours of a batch
     size_t batch_capacity = 0;      // in frames
-    int tune_shade_num = 3, tune_leaf_lanes = 8, tune_blocks_per_cu = 0, tune_batch = 16;
+    int tune_shade_num = 3, tune_leaf_lanes = 8, tune_blocks_per_cu = 0, tune_batch = 16, tune_sdone_lanes = 8;
 
     void free_scene()
     {
@@ -443,7 +461,7 @@ int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchPar
     uint64_t tiles = (uint64_t)((c->width + 7) / 8) * (uint64_t)((c->local_rows + 7) / 8) * bp.n_frames;
     uint64_t blocks = std::min<uint64_t>((uint64_t)c->n_cus * per_cu, (tiles + 3) / 4);
     if (blocks == 0) return RT_OK;
-    SchedParams sched{c->tune_shade_num, c->tune_leaf_lanes};
+    SchedParams sched{c->tune_shade_num, c->tune_leaf_lanes, c->tune_sdone_lanes};
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, c->view, fp, c->sm, c->local_rows, c->fb,
                        bp, counter, sched);
     RT_HIP_CHECK(hipGetLastError());
@@ -551,12 +569,12 @@ int rt_create(int device, int width, int height, int stripe_rows, int stripe_ind
         (e = hipMalloc((void **)&c->fb.accum, px * 3 * sizeof(float))) != hipSuccess ||
         (e = hipMalloc((void **)&c->fb.frame_f16, px * 4 * sizeof(uint16_t))) != hipSuccess ||
         (e = hipMalloc((void **)&c->fb.ids, px * sizeof(int32_t))) != hipSuccess ||
-        (e = hipMalloc((void **)&c->fb.counters, 8 * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->fb.counters, 16 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_work, kWorkCounters * sizeof(unsigned int))) != hipSuccess ||
         (e = hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess ||
         (e = hipMemsetAsync(c->fb.accum, 0, px * 3 * sizeof(float), c->stream)) != hipSuccess ||
         (e = hipMemsetAsync(c->fb.frame_f16, 0, px * 4 * sizeof(uint16_t), c->stream)) != hipSuccess ||
-        (e = hipMemsetAsync(c->fb.counters, 0, 8 * sizeof(unsigned long long), c->stream)) != hipSuccess) {
+        (e = hipMemsetAsync(c->fb.counters, 0, 16 * sizeof(unsigned long long), c->stream)) != hipSuccess) {
         return cleanup(fail(RT_ERR_DEVICE, std::string("rt_create: ") + hipGetErrorString(e)));
     }
     hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, c->stream, c->fb.ids, -2, px);
@@ -646,6 +664,7 @@ int rt_set_tuning(rt_context *c, int key, int value)
     case RT_TUNE_LEAF_LANES: if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "leaf_lanes out of range"); c->tune_leaf_lanes = value; break;
     case RT_TUNE_BLOCKS_PER_CU: if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "blocks_per_cu out of range"); c->tune_blocks_per_cu = value; break;
     case RT_TUNE_BATCH_FRAMES: if (value < 1 || value > 4096) return fail(RT_ERR_INVALID, "batch_frames out of range"); c->tune_batch = value; break;
+    case RT_TUNE_SHADOW_DONE_LANES: if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "shadow_done_lanes out of range"); c->tune_sdone_lanes = value; break;
     default: return fail(RT_ERR_INVALID, "unknown tuning key");
     }
     return RT_OK;
@@ -741,21 +760,21 @@ int rt_set_counting(rt_context *c, int enable)
     return RT_OK;
 }
 
-int rt_read_counters(rt_context *c, uint64_t counters[8])
+int rt_read_counters(rt_context *c, uint64_t counters[16])
 {
     if (!c || !counters) return fail(RT_ERR_INVALID, "null argument");
     RT_HIP_CHECK(hipSetDevice(c->device));
-    unsigned long long tmp[8];
+    unsigned long long tmp[16];
     RT_HIP_CHECK(hipMemcpyAsync(tmp, c->fb.counters, sizeof tmp, hipMemcpyDeviceToHost, c->stream));
     RT_HIP_CHECK(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 8; i++) counters[i] = tmp[i];
+    for (int i = 0; i < 16; i++) counters[i] = tmp[i];
     return RT_OK;
 }
 
 int rt_take_triangle_tests(rt_context *c, uint32_t *triangle_tests)
 {
     if (!c || !triangle_tests) return fail(RT_ERR_INVALID, "null argument");
-    uint64_t cnt[8];
+    uint64_t cnt[16];
     int rc = rt_read_counters(c, cnt);
     if (rc) return rc;
     uint64_t rays = cnt[0] - c->tests_taken_rays;

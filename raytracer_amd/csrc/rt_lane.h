@@ -1,20 +1,27 @@
 // rt_lane.h -- the path tracer as a per-lane state machine.
 //
 // The shader's loop nest (raytracer_compute.wgsl:189-278 inside :333-337) is
-// unrolled into resumable pieces so that the 64 lanes of a wave need not be at
-// the same sample, bounce or kind of ray:
+// cut into resumable pieces so that the 64 lanes of a wave need not be at the
+// same sample, bounce or kind of ray:
 //
-//   lane_begin_pixel  seed + camera ray, first path            (:293-336)
-//   lane_step_inner   one BVH node visit  } ray_all, for both the closest-hit
-//   lane_step_leaf    one BVH leaf visit  } query and the shadow query (:15-39)
-//   lane_shade        everything between two ray_all calls: hit record, light
-//                     sample and shadow-ray launch (:204-216), or shadow result,
-//                     emission, throughput, roulette, next direction (:219-274),
-//                     path end / next sample / pixel end (:198-201, :334-337)
+//   lane_begin_pixel   seed + camera ray, first path                     (:293-336)
+//   lane_step_inner    one BVH node visit      } ray_all for the closest-hit
+//   lane_step_triangle one triangle of a leaf  } and the shadow query   (:15-39)
+//   lane_shade_closest after a closest-hit ray: sky on a miss (:198-202); on a
+//                      hit the whole bounce at once -- light sample (:211-216)
+//                      and emission, throughput, roulette, next direction
+//                      (:229-274) -- which launches the shadow ray and parks the
+//                      next bounce ray, or launches the next ray directly
+//   lane_shadow_done   after a shadow ray: the two additions to `light` in the
+//                      shader's order (:223 then :242), then the parked ray,
+//                      the next sample or the end of the pixel
 //
-// Each lane always owns exactly one ray in flight (closest or shadow).  The
-// order of the random draws and of every f32 operation per lane is that of the
-// shader, so results do not depend on how lanes are scheduled.
+// Doing the bounce before its shadow ray is traced is legal because nothing in
+// :229-274 reads the shadow result; only the additions to `light` depend on it,
+// and those are replayed in order by lane_shadow_done.  The random draws per
+// lane stay in the shader's order (light pick, triangle point, roulette,
+// specular coin, hemisphere).  Each lane always owns exactly one ray in
+// flight, so results do not depend on how lanes are scheduled.
 #pragma once
 
 #include "rt_core.h"
@@ -22,10 +29,12 @@
 namespace rt {
 
 enum : int32_t {
-    kLaneNeedUnit = 0, // no pixel assigned
-    kLaneTraverse = 1, // ray in flight
-    kLaneShade = 2,    // ray finished, waiting for lane_shade
-    kLaneDead = 3      // no work left
+    kLaneNeedUnit = 0,     // no pixel assigned
+    kLaneTraverse = 1,     // ray in flight
+    kLaneShadeClosest = 2, // closest-hit ray finished
+    kLaneShadowDone = 3,   // shadow ray finished
+    kLanePixelDone = 4,    // all samples done; colour waits to be stored
+    kLaneDead = 5          // no work left
 };
 
 constexpr int32_t kNoHit = 0x7fffffff;
@@ -48,10 +57,10 @@ struct Lane {
     int32_t best_id; // closest: best id so far; shadow: kNoHit until an occluder is found
     int32_t cur;     // node link being visited; kNoRoot when the traversal is over
     bool anyhit;
-    // bounce suspended while its shadow ray is in flight
-    f3 in_o, in_d, nee;
-    float hit_t;
-    int32_t hit_id;
+    // parked while the shadow ray is in flight
+    f3 next_o, next_d; // next bounce ray
+    f3 nee, em;        // pending additions to light
+    bool has_em, path_continues;
 };
 
 RT_HD bool link_is_inner(int32_t cur) { return cur >= 0 && cur != kNoRoot; }
@@ -60,15 +69,17 @@ RT_HD bool link_is_leaf(int32_t cur) { return cur < 0; }
 template <class Stack>
 RT_HD void lane_pop(Lane &L, Stack &stack)
 {
-    if (stack.empty()) { L.cur = kNoRoot; L.mode = kLaneShade; }
+    if (stack.empty()) { L.cur = kNoRoot; L.mode = L.anyhit ? kLaneShadowDone : kLaneShadeClosest; }
     else L.cur = stack.pop();
 }
 
 // Starts ray_all for the lane's ray (L.o, L.d): spheres are tested here
 // (raytracer_compute.wgsl:19-24), triangles by the step functions.
 template <class Stack>
-RT_HD void lane_launch_ray(const SceneView &sc, Lane &L, Stack &stack, bool anyhit, float limit, TestCounts *cnt)
+RT_HD void lane_launch_ray(const SceneView &sc, Lane &L, Stack &stack, bool anyhit, float limit, uint32_t &n_rays,
+                           TestCounts *cnt)
 {
+    n_rays++;
     L.anyhit = anyhit;
     L.tmax = anyhit ? limit : INFINITY;
     L.best_id = kNoHit;
@@ -91,7 +102,7 @@ RT_HD void lane_launch_ray(const SceneView &sc, Lane &L, Stack &stack, bool anyh
         }
         L.rb = make_raybox(L.o, L.d);
     }
-    if (L.cur == kNoRoot) L.mode = kLaneShade;
+    if (L.cur == kNoRoot) L.mode = anyhit ? kLaneShadowDone : kLaneShadeClosest;
 }
 
 template <class Stack>
@@ -113,30 +124,53 @@ RT_HD void lane_step_inner(const SceneView &sc, Lane &L, Stack &stack, TestCount
     else lane_pop(L, stack);
 }
 
+// Tests the first triangle of the leaf L.cur and shrinks the leaf by it.
 template <class Stack>
-RT_HD void lane_step_leaf(const SceneView &sc, Lane &L, Stack &stack, TestCounts *cnt)
+RT_HD void lane_step_triangle(const SceneView &sc, Lane &L, Stack &stack, TestCounts *cnt)
 {
     uint32_t code = (uint32_t)~L.cur;
-    uint32_t first = code >> 3, count = (code & 7u) + 1u;
+    uint32_t first = code >> 3, left = code & 7u; // triangles after this one
+    const f4 *tr = sc.tri_isect + 3 * (size_t)first;
+    f4 a = tr[0], b = tr[1], c = tr[2];
+    float t = triangle_t(L.o, L.d, xyz(a), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x));
+    if (cnt) cnt->tris++;
     bool stop = false;
-    for (uint32_t k = 0; k < count && !stop; k++) {
-        const f4 *tr = sc.tri_isect + 3 * (size_t)(first + k);
-        f4 a = tr[0], b = tr[1], c = tr[2];
-        float t = triangle_t(L.o, L.d, xyz(a), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x));
-        if (cnt) cnt->tris++;
-        if (!(t > 0.0f)) continue;
+    if (t > 0.0f) {
         uint32_t orig = f2u(c.y);
         int32_t id = (int32_t)(orig + sc.n_spheres);
         bool candidate = L.anyhit ? !(t > L.tmax) : (t < L.tmax || (t == L.tmax && id < L.best_id));
-        if (!candidate) continue;
-        f3 nrm = xyz(sc.tri_shade[3 * (size_t)orig]); // common.wgsl:202-207
-        if (dot(nrm, L.d) > 0.0f) continue;
-        L.best_id = id;
-        if (L.anyhit) stop = true;
-        else L.tmax = t;
+        if (candidate) {
+            f3 nrm = xyz(sc.tri_shade[3 * (size_t)orig]); // common.wgsl:202-207
+            if (!(dot(nrm, L.d) > 0.0f)) {
+                L.best_id = id;
+                if (L.anyhit) stop = true;
+                else L.tmax = t;
+            }
+        }
     }
-    if (stop) { L.cur = kNoRoot; L.mode = kLaneShade; }
+    if (stop) { L.cur = kNoRoot; L.mode = kLaneShadowDone; }
+    else if (left != 0u) L.cur = (int32_t)~(((first + 1u) << 3) | (left - 1u));
     else lane_pop(L, stack);
+}
+
+// A path has ended with radiance L.light (raytracer_compute.wgsl:335-336).
+// Returns true when the lane must launch the camera ray again for its next
+// sample (L.o, L.d are set); false when the pixel is finished.
+RT_HD bool lane_end_path(const FrameParams &fp, Lane &L)
+{
+    L.total = add(L.total, L.light);
+    L.sample++;
+    if (L.sample < fp.spp) {
+        L.color = mk3(1.0f, 1.0f, 1.0f);
+        L.light = mk3(0.0f, 0.0f, 0.0f);
+        L.spec = false;
+        L.bounce = 0;
+        L.o = fp.cam_pos;
+        L.d = L.prim_d;
+        return true;
+    }
+    L.mode = kLanePixelDone;
+    return false;
 }
 
 // Seed, jitter, camera ray and the first path of a pixel (raytracer_compute.wgsl:293-336).
@@ -154,92 +188,76 @@ RT_HD void lane_begin_pixel(const SceneView &sc, const FrameParams &fp, Lane &L,
     L.bounce = 0;
     L.o = fp.cam_pos;
     L.d = L.prim_d;
-    n_rays++;
-    lane_launch_ray(sc, L, stack, false, 0.0f, cnt);
+    lane_launch_ray(sc, L, stack, false, 0.0f, n_rays, cnt);
 }
 
-// Consumes the finished ray of a lane in kLaneShade and either launches the
-// lane's next ray or finishes the pixel.  Returns true when the pixel is
-// finished; out_color is then its frame colour (raytracer_compute.wgsl:337).
+// Frame colour of a lane in kLanePixelDone (raytracer_compute.wgsl:337).
+RT_HD f3 lane_pixel_color(const FrameParams &fp, const Lane &L) { return divs(L.total, fp.spp_f); }
+
+// Lane in kLaneShadeClosest: consumes the closest-hit result.
 template <class Stack>
-RT_HD bool lane_shade(const SceneView &sc, const FrameParams &fp, Lane &L, Stack &stack, uint32_t &n_rays,
-                      f3 &out_color, TestCounts *cnt)
+RT_HD void lane_shade_closest(const SceneView &sc, const FrameParams &fp, Lane &L, Stack &stack, uint32_t &n_rays,
+                              TestCounts *cnt)
 {
-    bool path_end = false, launch = false, launch_anyhit = false, finish = false;
+    int32_t id = (L.best_id == kNoHit) ? -1 : L.best_id;
+    float t = L.tmax;
+    if (L.bounce == 0u && L.sample == 0u) L.primary_id = id;
+    bool end_path = false, launch = false, launch_anyhit = false;
     float launch_limit = 0.0f;
-    bool shadow_result = L.anyhit;
-    int32_t id;
-    float t;
-    if (shadow_result) {
-        if (L.best_id == kNoHit) L.light = add(L.light, L.nee); // raytracer_compute.wgsl:219-224
-        L.o = L.in_o;
-        L.d = L.in_d;
-        id = L.hit_id;
-        t = L.hit_t;
-        finish = true;
+    if (id < 0) { // raytracer_compute.wgsl:198-202
+        L.light = add(L.light, mul(scale(mk3(1.0f, 1.0f, 1.0f), 0.4f), L.color));
+        end_path = true;
     } else {
-        id = (L.best_id == kNoHit) ? -1 : L.best_id;
-        t = L.tmax;
-        if (L.bounce == 0u && L.sample == 0u) L.primary_id = id;
-        if (id < 0) { // raytracer_compute.wgsl:198-202
-            L.light = add(L.light, mul(scale(mk3(1.0f, 1.0f, 1.0f), 0.4f), L.color));
-            path_end = true;
-        }
-    }
-    if (!path_end) {
+        if (cnt) cnt->bounces++;
         Hit hit = fetch_hit(sc, L.o, L.d, id, t);
-        if (!shadow_result) {
-            if (cnt) cnt->bounces++;
-            f3 hit_point = add(L.o, scale(L.d, hit.t));
-            LightSample ts = sample_light_triangles(sc, hit_point, L.rng);
-            finish = true;
-            if (ts.pdf > 0.0f) {
-                float cos_theta = dot(hit.normal, ts.direction);
-                if (cos_theta > 0.0f) {
-                    L.nee = nee_contribution(ts, hit.normal, cos_theta, L.color);
-                    L.in_o = L.o;
-                    L.in_d = L.d;
-                    L.hit_t = t;
-                    L.hit_id = id;
-                    L.o = add(hit_point, scale(hit.normal, 0.01f));
-                    L.d = ts.direction;
-                    launch = true;
-                    launch_anyhit = true;
-                    launch_limit = ts.distance - 0.1f;
-                    finish = false;
-                }
+        f3 hit_point = add(L.o, scale(L.d, hit.t));
+        LightSample ts = sample_light_triangles(sc, hit_point, L.rng);
+        bool shadow = false;
+        if (ts.pdf > 0.0f) {
+            float cos_theta = dot(hit.normal, ts.direction);
+            if (cos_theta > 0.0f) {
+                L.nee = nee_contribution(ts, hit.normal, cos_theta, L.color);
+                shadow = true;
             }
         }
-        if (finish) {
-            bool alive = finish_bounce(hit, L.bounce, L.o, L.d, L.color, L.light, L.spec, L.rng);
-            L.bounce++;
-            if (alive && L.bounce < fp.max_bounces) launch = true;
-            else path_end = true;
-        }
-    }
-    bool pixel_done = false;
-    if (path_end) {
-        L.total = add(L.total, L.light);
-        L.sample++;
-        if (L.sample < fp.spp) { // raytracer_compute.wgsl:334-336: same camera ray, rng continues
-            L.color = mk3(1.0f, 1.0f, 1.0f);
-            L.light = mk3(0.0f, 0.0f, 0.0f);
-            L.spec = false;
-            L.bounce = 0;
-            L.o = fp.cam_pos;
-            L.d = L.prim_d;
+        f3 no = L.o, nd = L.d;
+        bool alive = finish_bounce(hit, L.bounce, no, nd, L.color, L.em, L.has_em, L.spec, L.rng);
+        L.bounce++;
+        bool cont = alive && L.bounce < fp.max_bounces;
+        if (shadow) {
+            L.next_o = no;
+            L.next_d = nd;
+            L.path_continues = cont;
+            L.o = add(hit_point, scale(hit.normal, 0.01f));
+            L.d = ts.direction;
             launch = true;
+            launch_anyhit = true;
+            launch_limit = ts.distance - 0.1f;
         } else {
-            out_color = divs(L.total, fp.spp_f);
-            L.mode = kLaneNeedUnit;
-            pixel_done = true;
+            if (L.has_em) L.light = add(L.light, L.em);
+            if (cont) { L.o = no; L.d = nd; launch = true; }
+            else end_path = true;
         }
     }
-    if (launch) {
-        n_rays++;
-        lane_launch_ray(sc, L, stack, launch_anyhit, launch_limit, cnt);
+    if (end_path) launch = lane_end_path(fp, L);
+    if (launch) lane_launch_ray(sc, L, stack, launch_anyhit, launch_limit, n_rays, cnt);
+}
+
+// Lane in kLaneShadowDone: consumes the shadow result (raytracer_compute.wgsl:219-224, :242).
+template <class Stack>
+RT_HD void lane_shadow_done(const SceneView &sc, const FrameParams &fp, Lane &L, Stack &stack, uint32_t &n_rays,
+                            TestCounts *cnt)
+{
+    if (L.best_id == kNoHit) L.light = add(L.light, L.nee);
+    if (L.has_em) L.light = add(L.light, L.em);
+    bool launch = true;
+    if (L.path_continues) {
+        L.o = L.next_o;
+        L.d = L.next_d;
+    } else {
+        launch = lane_end_path(fp, L);
     }
-    return pixel_done;
+    if (launch) lane_launch_ray(sc, L, stack, false, 0.0f, n_rays, cnt);
 }
 
 } // namespace rt

@@ -49,7 +49,11 @@ RT_HD f3 ray_trace(const SceneView &sc, f3 ro, f3 rd, uint32_t max_bounces, uint
                 if (reached) light = add(light, nee_contribution(ts, hit.normal, cos_theta, color));
             }
         }
-        if (!finish_bounce(hit, i, ro, rd, color, light, is_specular_bounce, state)) break;
+        f3 em;
+        bool has_em;
+        bool alive = finish_bounce(hit, i, ro, rd, color, em, has_em, is_specular_bounce, state);
+        if (has_em) light = add(light, em);
+        if (!alive) break;
     }
     return light;
 }

@@ -1,0 +1,197 @@
+'use strict';
+/*
+ * HipRenderer: drop-in for the reference's WebGPURenderer
+ * (src/webgpu-renderer.ts:20-322) on an AMD MI355X through librt_hip.so.
+ * Same construction contract (static async Create resolving to a renderer or
+ * null, never rejecting), same controls, same frame sequencing (frameIndex is
+ * incremented before the uniforms are written), same counter semantics.
+ * `canvas` only needs width and height; an optional `pixels` typed array on it
+ * receives the presented image.
+ *
+ * Added for headless use and parity checks (the reference never reads images
+ * back): renderFrames(n), sync(), readAccum(), readIds(), readFrameF16(),
+ * getCounters(), destroy().
+ */
+const path = require('path');
+const Common = require('./common');
+const { RethrownError } = Common;
+const { Accumulator } = require('./accumulator');
+const { FPSCounter } = require('./fps-counter');
+const Schemas = require('./gpu-schemas');
+
+function loadNative() {
+    return require(path.join(__dirname, 'rt_hip_napi.node'));
+}
+
+class HipRenderer {
+    constructor(canvas) {
+        // private in the reference (src/webgpu-renderer.ts:42-46)
+        this.canvas = canvas;
+        this.resolution = { width: canvas.width, height: canvas.height };
+        this.native = null;
+        this.handle = null;
+        this.accumulator = null;
+        this.currentScene = null;
+        this.frameIndex = 0;
+        this.fpsCounter = new FPSCounter();
+        this.samplesPerPixel = 1;
+        this.debugEnabled = false;
+        this._enabled = true;
+        this._loopTimer = null;
+    }
+
+    // src/webgpu-renderer.ts:48-103.  options: { device, maxBounces, stripeRows, stripeIndex, stripeCount }
+    static async Create(canvas, scenePath, options) {
+        const renderer = new HipRenderer(canvas);
+        const opt = options || {};
+        try {
+            try {
+                renderer.native = loadNative();
+                if (renderer.native.deviceCount() < 1) throw new Error('No HIP device found');
+                renderer.handle = renderer.native.create(
+                    opt.device || 0, renderer.resolution.width, renderer.resolution.height,
+                    opt.stripeRows || 8, opt.stripeIndex || 0, opt.stripeCount || 1);
+                if (opt.maxBounces !== undefined) renderer.native.setMaxBounces(renderer.handle, opt.maxBounces);
+            } catch (error) {
+                throw new RethrownError('Failed to create pipelines', error);
+            }
+            try {
+                renderer.currentScene = await Common.loadScene(scenePath);
+            } catch (error) {
+                throw new RethrownError("Failed to load '" + scenePath + "'", error);
+            }
+            try {
+                await renderer.createBuffersAndBindGroups();
+            } catch (error) {
+                throw new RethrownError('Failed to create scene buffer', error);
+            }
+        } catch (error) {
+            Common.showError(error.message);
+            return null;
+        }
+        return renderer;
+    }
+
+    // src/webgpu-renderer.ts:141-212
+    async createBuffersAndBindGroups() {
+        if (!this.handle) throw new Error('Device not initialized');
+        if (!this.currentScene) throw new Error('Scene not loaded');
+        const scene = this.currentScene;
+        this.native.setScene(this.handle, Schemas.packSpheres(scene.spheres), Schemas.packTriangles(scene.triangles));
+        this.writeUniforms();
+        this.accumulator = await Accumulator.create({ native: this.native, handle: this.handle }, this.resolution);
+    }
+
+    // src/webgpu-renderer.ts:214-230
+    writeUniforms() {
+        if (!this.handle || !this.currentScene) return;
+        this.native.setUniforms(this.handle, Schemas.packUniforms(
+            this.currentScene.camera, this.frameIndex, this.resolution.width, this.resolution.height,
+            this.samplesPerPixel, this.debugEnabled));
+    }
+
+    // src/webgpu-renderer.ts:232-235
+    setSamplesPerPixel(samples) {
+        this.samplesPerPixel = Math.max(1, Math.min(16, samples));
+        this.writeUniforms();
+    }
+
+    // src/webgpu-renderer.ts:237-268: no-op without resources; fire and forget
+    render() {
+        if (!this.handle || !this.accumulator) return;
+        this.frameIndex++;
+        this.writeUniforms();
+        this.native.renderFrame(this.handle);
+        this.accumulator.render(null, this.canvas.pixels);
+    }
+
+    // n calls of render() as one native submission
+    renderFrames(n) {
+        if (!this.handle || !this.accumulator || n <= 0) return;
+        const first = this.frameIndex + 1;
+        this.frameIndex += n;
+        this.native.renderFrames(this.handle, first, n);
+        this.writeUniforms();
+        this.accumulator.render(null, this.canvas.pixels);
+    }
+
+    // src/webgpu-renderer.ts:270-277 with setImmediate in place of requestAnimationFrame
+    startRenderLoop() {
+        const loop = () => {
+            this.fpsCounter.updateFPS();
+            if (this._enabled) {
+                this.render();
+                this.native.sync(this.handle);
+            }
+            this._loopTimer = setImmediate(loop);
+        };
+        this._loopTimer = setImmediate(loop);
+    }
+
+    stopRenderLoop() {
+        if (this._loopTimer) clearImmediate(this._loopTimer);
+        this._loopTimer = null;
+    }
+
+    setDebug(checked) {
+        this.debugEnabled = checked;
+        this.writeUniforms();
+    }
+
+    // src/webgpu-renderer.ts:284-287: frameIndex only; the planes keep their contents
+    resetAccumulation() {
+        this.frameIndex = 0;
+        this.writeUniforms();
+    }
+
+    getFPS() {
+        return this.fpsCounter.getFPS();
+    }
+
+    getEnabled() {
+        return this._enabled;
+    }
+
+    setEnabled(value) {
+        this._enabled = value;
+    }
+
+    // src/webgpu-renderer.ts:301-321: u32 counter, zeroed by the read
+    async getTriangleTestsSinceLastCheck() {
+        if (!this.handle) return 0;
+        return this.native.takeTriangleTests(this.handle);
+    }
+
+    sync() {
+        this.native.sync(this.handle);
+    }
+
+    readAccum() {
+        return this.native.readAccum(this.handle, this.resolution.width, this.resolution.height);
+    }
+
+    readIds() {
+        return this.native.readPrimaryIds(this.handle, this.resolution.width, this.resolution.height);
+    }
+
+    readFrameF16() {
+        return this.native.readFrameF16(this.handle, this.resolution.width, this.resolution.height);
+    }
+
+    getCounters() {
+        return this.native.readCounters(this.handle);
+    }
+
+    lastRenderMs() {
+        return this.native.lastRenderMs(this.handle);
+    }
+
+    destroy() {
+        this.stopRenderLoop();
+        if (this.handle) this.native.destroy(this.handle);
+        this.handle = null;
+        this.accumulator = null;
+    }
+}
+
+module.exports = { HipRenderer };

@@ -136,7 +136,10 @@ extern "C" int har_debug_pixel(const void *uniforms80, const void *spheres, uint
                     if (reached_b) light = rt::add(light, rt::nee_contribution(ts, hit.normal, ct, color));
                 }
             }
-            if (!rt::finish_bounce(hit, i, ro, rd, color, light, spec, state)) break;
+            rt::f3 em; bool has_em;
+            bool alive = rt::finish_bounce(hit, i, ro, rd, color, em, has_em, spec, state);
+            if (has_em) light = rt::add(light, em);
+            if (!alive) break;
         }
     }
     return mismatches;
@@ -215,7 +218,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
             if (!any_alive) break;
             for (;;) {
                 int n_trav = 0, n_shade = 0;
-                for (auto &l : L) { n_trav += l.mode == rt::kLaneTraverse; n_shade += l.mode == rt::kLaneShade; }
+                for (auto &l : L) { n_trav += l.mode == rt::kLaneTraverse; n_shade += l.mode == rt::kLaneShadeClosest; }
                 if (!n_trav) break;
                 if (n_shade && n_trav * 8 < (n_trav + n_shade) * shade_num) break;
                 for (int i = 0; i < 64; i++)
@@ -227,18 +230,23 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
                 }
                 if (n_leaf && (n_leaf >= leaf_lanes || !n_inner))
                     for (int i = 0; i < 64; i++)
-                        if (L[i].mode == rt::kLaneTraverse && rt::link_is_leaf(L[i].cur)) rt::lane_step_leaf(sc, L[i], st[i], nullptr);
+                        if (L[i].mode == rt::kLaneTraverse && rt::link_is_leaf(L[i].cur)) rt::lane_step_triangle(sc, L[i], st[i], nullptr);
+                for (int i = 0; i < 64; i++)
+                    if (L[i].mode == rt::kLaneShadowDone) rt::lane_shadow_done(sc, fp, L[i], st[i], n_rays, nullptr);
             }
             for (int i = 0; i < 64; i++) {
-                if (L[i].mode != rt::kLaneShade) continue;
-                rt::f3 c;
-                if (rt::lane_shade(sc, fp, L[i], st[i], n_rays, c, nullptr)) {
-                    size_t p = (size_t)L[i].py * W + L[i].px;
-                    uint16_t *dst = &batch[((size_t)L[i].frame_k * W * H + p) * 4];
-                    dst[0] = rt::f32_to_f16_bits(c.x); dst[1] = rt::f32_to_f16_bits(c.y);
-                    dst[2] = rt::f32_to_f16_bits(c.z); dst[3] = 0x3c00;
-                    if (L[i].frame_k + 1 == n_frames && ids) ids[p] = L[i].primary_id;
-                }
+                if (L[i].mode == rt::kLaneShadowDone) rt::lane_shadow_done(sc, fp, L[i], st[i], n_rays, nullptr);
+                if (L[i].mode == rt::kLaneShadeClosest) rt::lane_shade_closest(sc, fp, L[i], st[i], n_rays, nullptr);
+            }
+            for (int i = 0; i < 64; i++) {
+                if (L[i].mode != rt::kLanePixelDone) continue;
+                rt::f3 c = rt::lane_pixel_color(fp, L[i]);
+                size_t p = (size_t)L[i].py * W + L[i].px;
+                uint16_t *dst = &batch[((size_t)L[i].frame_k * W * H + p) * 4];
+                dst[0] = rt::f32_to_f16_bits(c.x); dst[1] = rt::f32_to_f16_bits(c.y);
+                dst[2] = rt::f32_to_f16_bits(c.z); dst[3] = 0x3c00;
+                if (L[i].frame_k + 1 == n_frames && ids) ids[p] = L[i].primary_id;
+                L[i].mode = rt::kLaneNeedUnit;
             }
         }
         rays += n_rays;

@@ -1,0 +1,20 @@
+"""Per-phase lane utilisation of the persistent kernel (instrumented build)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from raytracer_amd import capi, scene as S
+name = sys.argv[1] if len(sys.argv) > 1 else "suzanne"
+W, H, spp, frames = 1920, 1080, 16, 2
+sc = S.load_scene(S.scene_path(name))
+ctx = capi.Context(W, H)
+for k, n in enumerate(["SHADE", "LEAF", "BPC", "BATCH", "SDONE"]):
+    if "RT_" + n in os.environ: ctx.set_tuning(k, int(os.environ["RT_" + n]))
+ctx.set_scene(S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles))
+ctx.set_counting(True)
+ctx.set_uniforms(S.pack_uniforms(sc.camera, 1, W, H, spp))
+ctx.render_frames(1, frames); ctx.sync()
+c = [int(x) for x in ctx.read_counters()]
+rays = c[0]
+print({k: v for k, v in os.environ.items() if k.startswith("RT_")}, "ms/frame %.2f" % (ctx.last_render_ms() / frames))
+print("per ray: nodes %.2f tris %.2f spheres %.2f bounces %.3f" % (c[1] / rays, c[2] / rays, c[3] / rays, c[4] / rays))
+for nm, it, ln in (("inner", c[5], c[6]), ("tri", c[7], c[8]), ("shade", c[9], c[10]), ("sdone", c[11], c[12])):
+    print("%-6s wave-iterations %d  (%.2f per ray-of-wave)  active lanes/iter %.1f (%.0f%%)" % (nm, it, it * 64 / rays, ln / max(it, 1), 100 * ln / max(it, 1) / 64))

@@ -16,6 +16,10 @@ def lib():
     L.har_render_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int,
                                    C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.har_render_frame.restype = C.c_int
+    L.har_render_frames_lanes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
+                                          C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_int]
+    L.har_render_frames_lanes.restype = C.c_int
     return L
 
 
@@ -44,3 +48,14 @@ class HarnessRenderer:
                                      self.max_bounces, 1 if self.brute else 0, self.max_leaf, _p(self.accum),
                                      _p(self.frame_f16), _p(self.ids), _p(self.counters), os.cpu_count() or 1)
         assert rc == 0
+
+
+    def render_frames_lanes(self, spp, first_frame, n_frames, shade_num=3, leaf_lanes=8):
+        """The persistent kernel's per-lane state machine, 64 lanes per emulated wave."""
+        u = self.S.pack_uniforms(self.scene.camera, first_frame, self.width, self.height, spp)
+        rc = self.L.har_render_frames_lanes(_p(u), _p(self.spheres), len(self.spheres), _p(self.tris), len(self.tris),
+                                            self.max_bounces, first_frame, n_frames, shade_num, leaf_lanes,
+                                            _p(self.accum), _p(self.frame_f16), _p(self.ids), _p(self.counters),
+                                            os.cpu_count() or 1)
+        assert rc == 0
+        self.frame_index = first_frame + n_frames - 1

@@ -48,3 +48,24 @@ def test_axis_parallel_ray_regression(scenes):
 def test_max_bounces_parameter(scenes):
     compare(scenes["boxes"], 48, 27, 1, 4, False, max_bounces=8)
     compare(scenes["boxes"], 48, 27, 1, 4, False, max_bounces=1)
+
+
+@pytest.mark.parametrize("name,width,height,frames,spp,shade_num,leaf_lanes,max_bounces", [
+    ("spheres", 100, 61, 3, 4, 3, 8, 6),
+    ("boxes", 100, 61, 2, 4, 0, 1, 6),
+    ("suzanne", 100, 61, 2, 4, 8, 64, 6),
+    ("suzanne", 64, 36, 2, 4, 2, 16, 8),
+    ("spheres", 64, 36, 2, 16, 3, 8, 1),
+])
+def test_lane_state_machine_matches_oracle(scenes, name, width, height, frames, spp, shade_num, leaf_lanes, max_bounces):
+    """rt_lane.h driven by an emulated wave (the persistent kernel's schedule), frames batched."""
+    scene = scenes[name]
+    orc = O.OracleRenderer(scene, width, height, max_bounces=max_bounces)
+    orc.set_samples_per_pixel(spp)
+    orc.render_frames(frames)
+    har = HarnessRenderer(scene, width, height, max_bounces=max_bounces)
+    har.render_frames_lanes(spp, 1, frames, shade_num, leaf_lanes)
+    assert np.array_equal(har.ids, orc.ids)
+    assert np.array_equal(har.frame_f16, orc.frame_f16)
+    assert np.array_equal(har.accum, orc.accum)
+    assert int(har.counters[0]) == int(orc.counters[0])
