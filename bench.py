@@ -36,6 +36,7 @@ WIDTH, HEIGHT, SPP, MAX_BOUNCES = 1920, 1080, 16, 6
 PEAK_FP32_TFLOPS = 157.3  # MI355X FP32 vector peak (packed FMA), chip-level spec
 # algorithmic flop prices per test / per bounce ("Roofline accounting")
 F_BOX, F_TRI, F_SPH, F_SHADE = 24, 52, 31, 160
+BATCH_FRAMES = 16  # the library's default frames per launch (RT_TUNE_BATCH_FRAMES)
 
 
 def parse_args():
@@ -61,8 +62,7 @@ def cpu_baseline(scene, threads):
 
     # calibrate on 2 rows, then size the band for about 15 s
     rays, dt = run(540, 542)
-    rate = rays / max(dt, 1e-6)
-    rows = int(max(2, min(HEIGHT // 2, round(15.0 * rate / (rays / 2.0)))))
+    rows = int(max(2, min(HEIGHT // 2, round(2 * 15.0 / max(dt, 1e-3)))))
     y0 = (HEIGHT - rows) // 2
     rays, dt = run(y0, y0 + rows)
     return {
@@ -93,13 +93,22 @@ def main():
         raise SystemExit("--gpus must equal WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the renderer)")
-    torch.cuda.set_device(local_rank)
+    # Rehearsal on a one-GPU box: RT_BENCH_REHEARSE=1 puts every rank on GPU 0 and gathers over gloo
+    # (RCCL refuses two ranks on one device).  The driver's real runs use one GPU per rank and RCCL.
+    rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
+    device = 0 if rehearse else local_rank
+    torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+
+    from raytracer_amd import sharding
 
     scene = S.load_scene(S.scene_path(SCENE))
     spheres, tris = S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles)
-    ctx = capi.Context(WIDTH, HEIGHT, device=local_rank, stripe_rows=8, stripe_index=rank, stripe_count=world)
+    ctx = capi.Context(WIDTH, HEIGHT, device=device, stripe_rows=8, stripe_index=rank, stripe_count=world)
     ctx.set_max_bounces(MAX_BOUNCES)
     ctx.set_scene(spheres, tris)
     ctx.set_uniforms(S.pack_uniforms(scene.camera, 1, WIDTH, HEIGHT, SPP))
@@ -113,40 +122,51 @@ def main():
         torch.cuda.synchronize()
         ctx.sync()
 
-    gather_buf = None
     own = ctx.owned_rows()
-    if world > 1:
-        gather_buf = torch.empty(3 * own * WIDTH, dtype=torch.float32, device="cuda")
+    local_rows = torch.empty((3, own, WIDTH), dtype=torch.float32, device="cuda") if world > 1 else None
 
-    # warmup (frames 1..W*frames_per_step), then the accumulator restarts at frame 1
+    # warmup (frames 1..W*frames_per_step); the timed run then restarts at frame 1
     if W > 0:
         ctx.render_frames(1, W * frames_per_step)
     barrier()
 
     rays_before = int(ctx.read_counters()[0])
-    kernel_ms = 0.0
     barrier()
     t0 = time.perf_counter()
     ctx.render_frames(1, K * frames_per_step)
     if world > 1:
         # combine: every rank contributes its rows; rank 0 assembles the image
-        ctx.export_owned_rows(gather_buf.data_ptr())
+        ctx.export_owned_rows(local_rows.data_ptr())
         ctx.sync()
-        rows = torch.tensor([own], device="cuda")
-        all_rows = [torch.zeros_like(rows) for _ in range(world)]
-        dist.all_gather(all_rows, rows)
-        bufs = [torch.empty(3 * int(r.item()) * WIDTH, dtype=torch.float32, device="cuda") for r in all_rows]
-        dist.all_gather(bufs, gather_buf)
+        blocks = sharding.all_gather_rows(local_rows.cpu() if rehearse else local_rows, world)
         if rank == 0:
-            for src, b in enumerate(bufs):
+            for src, block in enumerate(blocks):
                 if src != 0:
-                    ctx.import_rows(b.data_ptr(), src)
+                    block = block.cuda().contiguous()
+                    torch.cuda.synchronize()
+                    ctx.import_rows(block.data_ptr(), src)
+            ctx.sync()
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms = ctx.last_render_ms()
     rays = int(ctx.read_counters()[0]) - rays_before
 
-    t = torch.tensor([dt, float(rays), kernel_ms], dtype=torch.float64, device="cuda")
+    if world > 1 and rank == 0 and os.environ.get("RT_BENCH_VERIFY") == "1":
+        # the assembled image must equal what one GPU renders for the same frames (after the same warmup)
+        ref = capi.Context(WIDTH, HEIGHT, device=device)
+        ref.set_max_bounces(MAX_BOUNCES)
+        ref.set_scene(spheres, tris)
+        ref.set_uniforms(S.pack_uniforms(scene.camera, 1, WIDTH, HEIGHT, SPP))
+        if W > 0:
+            ref.render_frames(1, W * frames_per_step)
+        ref.render_frames(1, K * frames_per_step)
+        same = bool(np.array_equal(ref.read_accum(), ctx.read_accum()))
+        ref.close()
+        print("verify: assembled image bit-identical to the single-GPU render: %s" % same, file=sys.stderr)
+        if not same:
+            raise SystemExit("verification failed")
+
+    t = torch.tensor([dt, float(rays), kernel_ms], dtype=torch.float64, device="cpu" if rehearse else "cuda")
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -159,7 +179,7 @@ def main():
         return
 
     # roofline: algorithmic flops of the timed launches / HIP-event time of those launches
-    cctx = capi.Context(WIDTH, HEIGHT, device=local_rank)
+    cctx = capi.Context(WIDTH, HEIGHT, device=device)
     cctx.set_max_bounces(MAX_BOUNCES)
     cctx.set_scene(spheres, tris)
     cctx.set_counting(True)
@@ -168,10 +188,16 @@ def main():
     cnt = [int(x) for x in cctx.read_counters()]
     cctx.close()
     c_rays, c_boxpairs, c_tris, c_sph, c_bounces = cnt[0], cnt[1], cnt[2], cnt[3], cnt[4]
+    lane_util = None
+    if cnt[5]:
+        lane_util = {"inner": cnt[6] / cnt[5] / 64, "triangle": cnt[8] / max(cnt[7], 1) / 64,
+                     "shade": cnt[10] / max(cnt[9], 1) / 64, "shadow_done": cnt[12] / max(cnt[11], 1) / 64}
     flops_per_ray = (2 * c_boxpairs * F_BOX + c_tris * F_TRI + c_sph * F_SPH + c_bounces * F_SHADE) / c_rays
     brute_flops_per_ray = F_SPH * len(spheres) + F_TRI * len(tris)
-    rays_per_launch = rays / world / (K * frames_per_step)
-    launch_ms = kernel_ms / (K * frames_per_step)
+    frames = K * frames_per_step
+    launches = (frames + BATCH_FRAMES - 1) // BATCH_FRAMES   # rt_render_frames traces up to BATCH_FRAMES frames per launch
+    rays_per_launch = rays / world / launches
+    launch_ms = kernel_ms / launches
     achieved = flops_per_ray * rays_per_launch / (launch_ms * 1e-3) / 1e12
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -210,12 +236,15 @@ def main():
             "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_TFLOPS,
             "traffic": traffic,
-            "kernel": "path-trace + accumulate launch (one frame)",
+            "kernel": "render_persistent_kernel (path trace of up to %d frames per launch; the ordered accumulate kernel "
+                      "that follows it is included in the timing and is < 0.1%% of it)" % BATCH_FRAMES,
+            "launches": launches,
             "kernel_ms_per_launch": launch_ms,
             "flops_per_ray": flops_per_ray,
             "rays_per_launch": rays_per_launch,
             "per_ray": {"box_tests": 2 * c_boxpairs / c_rays, "triangle_tests": c_tris / c_rays,
                         "sphere_tests": c_sph / c_rays, "bounces": c_bounces / c_rays},
+            "lane_utilisation": lane_util,
             "brute_force_equivalent": {"flops_per_ray": brute_flops_per_ray,
                                        "tflops": brute_flops_per_ray * rays_per_launch / (launch_ms * 1e-3) / 1e12},
         },

@@ -93,6 +93,9 @@ __device__ inline void store_pixel(const rt::FrameParams &fp, const FrameBuffers
 // reference's @workgroup_size(8, 8); four tiles per 256-thread block.
 // ---------------------------------------------------------------------------
 constexpr int kBlock = 256;
+#ifndef RT_MINW
+#define RT_MINW 5 // waves per SIMD the persistent kernel is compiled for (<= 96 VGPRs; measured best)
+#endif
 
 template <bool BRUTE, int STACK, bool COUNT>
 __global__ __launch_bounds__(kBlock) void render_tiles_kernel(rt::SceneView sc, rt::FrameParams fp, StripeMap sm,
@@ -160,7 +163,7 @@ struct BatchParams {
 };
 
 template <int STACK, bool COUNT, bool FUSED>
-__global__ __launch_bounds__(kBlock) void render_persistent_kernel(rt::SceneView sc, rt::FrameParams fp, StripeMap sm,
+__global__ __launch_bounds__(kBlock, RT_MINW) void render_persistent_kernel(rt::SceneView sc, rt::FrameParams fp, StripeMap sm,
                                                                     int local_rows, FrameBuffers fb, BatchParams bp,
                                                                     unsigned int *work_counter, SchedParams sched)
 {
@@ -409,7 +412,7 @@ struct rt_context {
     uint32_t work_used = 0;
     uint2 *d_batch = nullptr;       // frame colours of a batch
     size_t batch_capacity = 0;      // in frames
-    int tune_shade_num = 3, tune_leaf_lanes = 8, tune_blocks_per_cu = 0, tune_batch = 16, tune_sdone_lanes = 8;
+    int tune_shade_num = 2, tune_leaf_lanes = 8, tune_blocks_per_cu = 0, tune_batch = 16, tune_sdone_lanes = 2;
 
     void free_scene()
     {

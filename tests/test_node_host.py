@@ -1,0 +1,100 @@
+"""The JavaScript host (raytracer_amd/js): loaders and packers against the Python
+mirror without a GPU; HipRenderer through the N-API addon against the oracle on
+the GPU box.  Node 12 is the runtime the image provides."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from raytracer_amd import scene as S
+from tests import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JS = os.path.join(ROOT, "raytracer_amd", "js")
+NODE = shutil.which("node")
+
+pytestmark = pytest.mark.skipif(NODE is None, reason="node is not installed")
+
+
+def node(script, *args):
+    out = subprocess.run([NODE, "-e", script] + list(args), capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return out.stdout
+
+
+@pytest.mark.parametrize("name", ["spheres", "boxes", "suzanne"])
+def test_js_loader_and_packers_match_python(name, tmp_path):
+    script = """
+const C = require('%s/common'), G = require('%s/gpu-schemas'), fs = require('fs');
+C.loadScene(process.argv[1]).then((s) => {
+  fs.writeFileSync(process.argv[2] + '.sp', Buffer.from(G.packSpheres(s.spheres).buffer));
+  fs.writeFileSync(process.argv[2] + '.tr', Buffer.from(G.packTriangles(s.triangles).buffer));
+  fs.writeFileSync(process.argv[2] + '.un', Buffer.from(G.packUniforms(s.camera, 7, 640, 360, 16, true).buffer));
+});
+""" % (JS, JS)
+    node(script, S.scene_path(name), str(tmp_path / "o"))
+    sc = S.load_scene(S.scene_path(name))
+    assert np.array_equal(np.fromfile(tmp_path / "o.sp", np.float32).reshape(-1, 16), S.pack_spheres(sc.spheres))
+    assert np.array_equal(np.fromfile(tmp_path / "o.tr", np.float32).reshape(-1, 24), S.pack_triangles(sc.triangles))
+    assert np.array_equal(np.fromfile(tmp_path / "o.un", np.float32), S.pack_uniforms(sc.camera, 7, 640, 360, 16, True))
+
+
+def test_js_obj_parser_quirks():
+    script = """
+const C = require('%s/common');
+const t = C.parseOBJ(['v 0 0 0','v 1 0 0','v 1 1 0','v 0 1 0','vn 0 0 1','f 1//1 2//1 3//1 4//1','f 1/9/1 2/9/1 3/9/1','f 1 2'].join('\\n')).triangles;
+const bad = C.parseOBJ('v 0 0 0\\nv 1 0 0\\nv 1 1 0\\nvn 0 0 1\\nf 1 2 3').triangles;
+console.log(JSON.stringify({n: t.length, second: t[1], bad: bad.length, badv0: bad[0].v0 === undefined}));
+""" % JS
+    r = json.loads(node(script))
+    assert r["n"] == 3 and r["second"]["v1"] == [1, 1, 0] and r["second"]["v2"] == [0, 1, 0]
+    # without a normal index every vertex is skipped and the triangle is left without vertices, as in the reference
+    assert r["bad"] == 1 and r["badv0"] is True
+
+
+def test_addon_exports_the_abi():
+    script = "const a = require('%s/rt_hip_napi.node'); console.log(JSON.stringify(Object.keys(a).sort()))" % JS
+    names = json.loads(node(script))
+    for n in ["create", "destroy", "setScene", "setUniforms", "renderFrame", "renderFrames", "readAccum",
+              "readPrimaryIds", "readFrameF16", "takeTriangleTests", "readCounters", "deviceCount", "sync"]:
+        assert n in names
+
+
+def test_create_resolves_null_on_failure():
+    # a missing scene file: Create reports the error and resolves to null, it never rejects
+    # (src/webgpu-renderer.ts:97-100); without a GPU it fails even earlier, same outcome
+    script = """
+const { HipRenderer } = require('%s/hip-renderer');
+HipRenderer.Create({ width: 16, height: 9 }, '/nonexistent/scene.json').then((r) => console.log(r === null ? 'NULL' : 'OBJ'));
+""" % JS
+    assert node(script).strip().endswith("NULL")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("per_frame", [False, True])
+def test_js_renderer_matches_oracle(scenes, tmp_path, per_frame):
+    width, height, frames, spp = 96, 54, 3, 4
+    args = [NODE, os.path.join(JS, "cli.js"), "--scene", S.scene_path("suzanne"), "--width", str(width), "--height",
+            str(height), "--spp", str(spp), "--frames", str(frames), "--dump", str(tmp_path / "d"), "--ppm",
+            str(tmp_path / "img.ppm")] + (["--per-frame"] if per_frame else [])
+    out = subprocess.run(args, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    orc = O.OracleRenderer(scenes["suzanne"], width, height)
+    orc.set_samples_per_pixel(spp)
+    orc.render_frames(frames)
+    assert np.array_equal(np.fromfile(tmp_path / "d.ids.i32", np.int32).reshape(height, width), orc.ids)
+    assert np.array_equal(np.fromfile(tmp_path / "d.frame.f16", np.uint16).reshape(height, width, 4), orc.frame_f16)
+    acc = np.fromfile(tmp_path / "d.accum.f32", np.float32).reshape(height, width, 3)
+    assert np.array_equal(acc, orc.accum_rgb())
+    assert info["rays"] == int(orc.counters[0]) and info["frame_index"] == frames
+    assert info["triangle_tests_u32"] == (int(orc.counters[0]) * 982) % 2**32
+    # presented image = accumulator as 8-bit unorm, no gamma (accumulator.wgsl:67)
+    ppm = (tmp_path / "img.ppm").read_bytes()
+    header = ("P6\n%d %d\n255\n" % (width, height)).encode()
+    assert ppm.startswith(header)
+    img = np.frombuffer(ppm[len(header):], np.uint8).reshape(height, width, 3)
+    assert np.array_equal(img, np.floor(orc.accum_rgb().astype(np.float64) * 255 + 0.5).astype(np.uint8))

@@ -1,0 +1,58 @@
+"""The two independent restatements of the reference shaders -- plain C
+(oracle/wgsl_oracle.c) and numpy float32 scalars (oracle/wgsl_numpy.py) -- must
+agree bit for bit.  The reference has no runnable form here, so this is the
+strongest pin the oracle can get; see the header of oracle/wgsl_oracle.h."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from raytracer_amd import scene as S
+from tests import oracle_lib as O
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import wgsl_numpy as N  # noqa: E402
+
+
+def test_sincos_agree():
+    for x in np.linspace(-7, 7, 1501).astype(np.float32):
+        s, c = O.sincos(float(x))
+        ns, nc = N.sincos(x)
+        assert (np.float32(s), np.float32(c)) == (ns, nc)
+
+
+def test_primitives_agree(scenes):
+    sc = scenes["spheres"]
+    spheres, tris = S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles)
+    rng = np.random.default_rng(7)
+    for _ in range(300):
+        o = rng.uniform([-2.4, 0.1, -4.9], [2.4, 4.9, -0.1]).astype(np.float32)
+        d = rng.normal(size=3).astype(np.float32)
+        d = (d / np.float32(np.sqrt(np.dot(d, d)))).astype(np.float32)
+        a = O.ray_all(o, d, spheres, tris)
+        b = N.ray_all(N.Scene(spheres, tris), o, d)
+        assert a.id == b.id and np.float32(a.t) == b.t
+        if a.id >= 0:
+            assert np.array_equal(np.array(a.normal[:], np.float32), b.normal)
+
+
+@pytest.mark.parametrize("name,width,height,frames,spp", [
+    ("spheres", 24, 14, 2, 2),
+    ("boxes", 16, 9, 1, 3),
+])
+def test_frames_agree(scenes, name, width, height, frames, spp):
+    sc = scenes[name]
+    spheres, tris = S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles)
+    orc = O.OracleRenderer(sc, width, height)
+    orc.set_samples_per_pixel(spp)
+    accum = np.zeros((3, height, width), np.float32)
+    rays = 0
+    for f in range(1, frames + 1):
+        orc.render()
+        frame, ids, r = N.render_frame(S.pack_uniforms(sc.camera, f, width, height, spp), spheres, tris, accum)
+        rays += r
+        assert np.array_equal(ids, orc.ids)
+        assert np.array_equal(frame, orc.frame_f16)
+    assert np.array_equal(accum, orc.accum)
+    assert rays == int(orc.counters[0])
