@@ -60,7 +60,8 @@ def cpu_baseline(scene, threads):
         orc.render()
         return int(orc.counters[0]), time.perf_counter() - t
 
-    # calibrate on 2 rows, then size the band for about 15 s
+    # warm up (library load, thread start), calibrate on 2 rows, then size the band for about 15 s
+    run(540, 541)
     rays, dt = run(540, 542)
     rows = int(max(2, min(HEIGHT // 2, round(2 * 15.0 / max(dt, 1e-3)))))
     y0 = (HEIGHT - rows) // 2
