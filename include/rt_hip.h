@@ -156,13 +156,18 @@ int rt_read_primary_ids(rt_context *ctx, int32_t *ids);
 
 /*
  * Cumulative 64-bit counters since creation:
- *   [0] rays traced (calls of the reference's ray_all: closest-hit + shadow)
+ *   [0] ray_all calls as the reference makes them (closest-hit + shadow); this is
+ *       the count behind rt_take_triangle_tests
+ *   [13] rays actually traversed: the persistent kernel traces the camera ray
+ *       of a pixel once per frame and reuses its hit for the frame's other
+ *       samples, which the shader starts on the same ray
+ *       (public/raytracer_compute.wgsl:329-336)
  *   [1] node visits (each tests the two child boxes of one node)
  *   [2] triangle tests   [3] sphere tests   [4] bounces (shaded hits)
  *   persistent kernel only, per wave: [5] inner-step iterations, [6] lanes active
  *   in them, [7] leaf-step iterations, [8] lanes active in them, [9] shade
  *   passes, [10] lanes active in them, [11] shadow hand-over steps, [12] lanes
- *   active in them; [13..15] reserved, 0
+ *   active in them; [14..15] reserved, 0
  * [1..12] advance only while counting is enabled (rt_set_counting), which
  * selects an instrumented build of the same kernel; timings are taken with
  * counting off.  [0] always advances.

@@ -107,8 +107,10 @@ RT_HD float luminance(f3 c) { return dot(c, mk3(0.2126f, 0.7152f, 0.0722f)); }
 // nodes      4 x f4 per node: child boxes (lo0,hi0,lo1,hi1 packed) + two child
 //            links.  A link >= 0 is a node index; a link < 0 encodes a leaf as
 //            ~((first << 3) | (count - 1)) over tri_isect.
-// tri_isect  3 x f4 per triangle in leaf order:
+// tri_isect  4 x f4 per triangle in leaf order:
 //            (v0.xyz, e01.x) (e01.yz, e02.xy) (e02.z, bits(original index), 0, 0)
+//            (unit normal.xyz, 0) -- a copy of tri_shade's, so that the back-face
+//            test needs no dependent fetch
 // tri_shade  3 x f4 per triangle in original order:
 //            (normal.xyz, smoothness) (color.xyz, specularProbability)
 //            (emissionColor*emissionStrength, 0)
@@ -135,6 +137,10 @@ struct SceneView {
 };
 
 constexpr int32_t kNoRoot = 0x7fffffff;
+#ifndef RT_TRI_RECORD
+#define RT_TRI_RECORD 4
+#endif
+constexpr int kTriRecord = RT_TRI_RECORD; // f4 per tri_isect record: 3 = without the normal copy, 4 = with it
 
 // Per-frame constants derived from the 80-byte uniforms on the host.
 // raytracer_compute.wgsl:290-316 computes these per pixel from the same inputs.
@@ -291,15 +297,15 @@ RT_HD int32_t trace_closest(const SceneView &sc, f3 ro, f3 rd, Stack &stack, flo
                 uint32_t code = (uint32_t)~cur;
                 uint32_t first = code >> 3, count = (code & 7u) + 1u;
                 for (uint32_t k = 0; k < count; k++) {
-                    const f4 *tr = sc.tri_isect + 3 * (size_t)(first + k);
-                    f4 a = tr[0], b = tr[1], c = tr[2];
+                    const f4 *tr = sc.tri_isect + kTriRecord * (size_t)(first + k);
+                    f4 a = tr[0], b = tr[1], c = tr[2], nq = kTriRecord == 4 ? tr[3] : sc.tri_shade[3 * (size_t)f2u(tr[2].y)];
                     float t = triangle_t(ro, rd, xyz(a), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x));
                     if (cnt) cnt->tris++;
                     if (!(t > 0.0f)) continue;
                     int32_t id = (int32_t)(f2u(c.y) + sc.n_spheres);
                     if (t < best_t || (t == best_t && id < best_id)) {
                         // common.wgsl:202-207 back-face cull on the stored unit normal
-                        f3 nrm = xyz(sc.tri_shade[3 * (size_t)f2u(c.y)]);
+                        f3 nrm = xyz(nq);
                         if (dot(nrm, rd) > 0.0f) continue;
                         best_t = t;
                         best_id = id;
@@ -348,12 +354,12 @@ RT_HD bool trace_occluded(const SceneView &sc, f3 ro, f3 rd, float limit, Stack 
             uint32_t code = (uint32_t)~cur;
             uint32_t first = code >> 3, count = (code & 7u) + 1u;
             for (uint32_t k = 0; k < count; k++) {
-                const f4 *tr = sc.tri_isect + 3 * (size_t)(first + k);
-                f4 a = tr[0], b = tr[1], c = tr[2];
+                const f4 *tr = sc.tri_isect + kTriRecord * (size_t)(first + k);
+                f4 a = tr[0], b = tr[1], c = tr[2], nq = kTriRecord == 4 ? tr[3] : sc.tri_shade[3 * (size_t)f2u(tr[2].y)];
                 float t = triangle_t(ro, rd, xyz(a), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x));
                 if (cnt) cnt->tris++;
                 if (!(t > 0.0f) || t > limit) continue;
-                f3 nrm = xyz(sc.tri_shade[3 * (size_t)f2u(c.y)]);
+                f3 nrm = xyz(nq);
                 if (dot(nrm, rd) > 0.0f) continue;
                 return true;
             }

@@ -120,7 +120,10 @@ __global__ __launch_bounds__(kBlock) void render_tiles_kernel(rt::SceneView sc, 
         }
     }
     uint32_t total = wave_sum(n_rays);
-    if (lane == 0 && total) atomicAdd(fb.counters, (unsigned long long)total);
+    if (lane == 0 && total) {
+        atomicAdd(fb.counters, (unsigned long long)total);
+        atomicAdd(fb.counters + 13, (unsigned long long)total);
+    }
     if (COUNT) {
         uint32_t b = wave_sum(cnt.boxes), t = wave_sum(cnt.tris), s = wave_sum(cnt.spheres), h = wave_sum(cnt.bounces);
         if (lane == 0) {
@@ -179,12 +182,14 @@ __global__ __launch_bounds__(kBlock, RT_MINW) void render_persistent_kernel(rt::
 
     rt::Lane L;
     L.mode = rt::kLaneNeedUnit;
-    uint32_t n_rays = 0;
+    rt::RayCounts n_rays = {0u, 0u};
     rt::TestCounts cnt = {0, 0, 0, 0};
     rt::TestCounts *cp = COUNT ? &cnt : nullptr;
 
     uint32_t ph_inner_it = 0, ph_inner_ln = 0, ph_leaf_it = 0, ph_leaf_ln = 0, ph_shade_it = 0, ph_shade_ln = 0,
              ph_sdone_it = 0, ph_sdone_ln = 0; // COUNT only
+    unsigned long long tc_inner = 0, tc_tri = 0, tc_sdone = 0, tc_shade = 0, tc_total = 0, tc0 = 0, tc_begin = 0; // COUNT only: wave cycles per phase
+    if (COUNT) tc_begin = clock64();
     uint32_t pool_tile = 0, pool_next = 64; // wave-uniform: current tile and next unused slot in it
     bool exhausted = false;                 // wave-uniform: the global counter has run out
 
@@ -259,33 +264,42 @@ __global__ __launch_bounds__(kBlock, RT_MINW) void render_persistent_kernel(rt::
             if (n_ready != 0 && (n_trav + n_sdone) * 8 < (n_trav + n_sdone + n_ready) * sched.shade_num) break;
 
             bool inner = L.mode == rt::kLaneTraverse && rt::link_is_inner(L.cur);
-            if (COUNT) { int n_in = __popcll(__ballot(inner)); if (n_in) { ph_inner_it++; ph_inner_ln += n_in; } }
+            if (COUNT) { int n_in = __popcll(__ballot(inner)); if (n_in) { ph_inner_it++; ph_inner_ln += n_in; } tc0 = clock64(); }
             if (inner) rt::lane_step_inner(sc, L, stack, cp);
+            if (COUNT) tc_inner += clock64() - tc0;
 
             bool leaf = L.mode == rt::kLaneTraverse && rt::link_is_leaf(L.cur);
             int n_leaf = __popcll(__ballot(leaf));
             bool any_inner = __ballot(L.mode == rt::kLaneTraverse && rt::link_is_inner(L.cur)) != 0ull;
             if (n_leaf != 0 && (n_leaf >= sched.leaf_lanes || !any_inner)) {
-                if (COUNT) { ph_leaf_it++; ph_leaf_ln += n_leaf; }
+                if (COUNT) { ph_leaf_it++; ph_leaf_ln += n_leaf; tc0 = clock64(); }
                 if (leaf) rt::lane_step_triangle(sc, L, stack, cp);
+                if (COUNT) tc_tri += clock64() - tc0;
             }
 
             // shadow rays that have finished: add their light, start the parked ray
             bool sdone = L.mode == rt::kLaneShadowDone;
             n_sdone = __popcll(__ballot(sdone));
             if (n_sdone != 0 && (n_sdone >= sched.sdone_lanes || __ballot(L.mode == rt::kLaneTraverse) == 0ull)) {
-                if (COUNT) { ph_sdone_it++; ph_sdone_ln += n_sdone; }
+                if (COUNT) { ph_sdone_it++; ph_sdone_ln += n_sdone; tc0 = clock64(); }
                 if (sdone) rt::lane_shadow_done(sc, fp, L, stack, n_rays, cp);
+                if (COUNT) tc_sdone += clock64() - tc0;
             }
         }
 
         // ---- shade the lanes whose closest-hit ray is finished ------------------------------------
         if (COUNT) { int n_sh = __popcll(__ballot(L.mode == rt::kLaneShadeClosest)); if (n_sh) { ph_shade_it++; ph_shade_ln += n_sh; } }
+        if (COUNT) tc0 = clock64();
         if (L.mode == rt::kLaneShadeClosest) rt::lane_shade_closest(sc, fp, L, stack, n_rays, cp);
+        if (COUNT) tc_shade += clock64() - tc0;
     }
+    if (COUNT) tc_total = clock64() - tc_begin;
 
-    uint32_t total = wave_sum(n_rays);
-    if (lane == 0 && total) atomicAdd(fb.counters, (unsigned long long)total);
+    uint32_t total = wave_sum(n_rays.calls), total_trav = wave_sum(n_rays.traversed);
+    if (lane == 0 && total) {
+        atomicAdd(fb.counters, (unsigned long long)total);
+        atomicAdd(fb.counters + 13, (unsigned long long)total_trav);
+    }
     if (COUNT) {
         uint32_t b = wave_sum(cnt.boxes), t = wave_sum(cnt.tris), s = wave_sum(cnt.spheres), h = wave_sum(cnt.bounces);
         if (lane == 0) {
@@ -301,6 +315,11 @@ __global__ __launch_bounds__(kBlock, RT_MINW) void render_persistent_kernel(rt::
             atomicAdd(fb.counters + 10, (unsigned long long)ph_shade_ln);
             atomicAdd(fb.counters + 11, (unsigned long long)ph_sdone_it);
             atomicAdd(fb.counters + 12, (unsigned long long)ph_sdone_ln);
+            atomicAdd(fb.counters + 16, tc_inner);
+            atomicAdd(fb.counters + 17, tc_tri);
+            atomicAdd(fb.counters + 18, tc_sdone);
+            atomicAdd(fb.counters + 19, tc_shade);
+            atomicAdd(fb.counters + 20, tc_total);
         }
     }
 }
@@ -572,12 +591,12 @@ int rt_create(int device, int width, int height, int stripe_rows, int stripe_ind
         (e = hipMalloc((void **)&c->fb.accum, px * 3 * sizeof(float))) != hipSuccess ||
         (e = hipMalloc((void **)&c->fb.frame_f16, px * 4 * sizeof(uint16_t))) != hipSuccess ||
         (e = hipMalloc((void **)&c->fb.ids, px * sizeof(int32_t))) != hipSuccess ||
-        (e = hipMalloc((void **)&c->fb.counters, 16 * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->fb.counters, 24 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_work, kWorkCounters * sizeof(unsigned int))) != hipSuccess ||
         (e = hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess ||
         (e = hipMemsetAsync(c->fb.accum, 0, px * 3 * sizeof(float), c->stream)) != hipSuccess ||
         (e = hipMemsetAsync(c->fb.frame_f16, 0, px * 4 * sizeof(uint16_t), c->stream)) != hipSuccess ||
-        (e = hipMemsetAsync(c->fb.counters, 0, 16 * sizeof(unsigned long long), c->stream)) != hipSuccess) {
+        (e = hipMemsetAsync(c->fb.counters, 0, 24 * sizeof(unsigned long long), c->stream)) != hipSuccess) {
         return cleanup(fail(RT_ERR_DEVICE, std::string("rt_create: ") + hipGetErrorString(e)));
     }
     hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, c->stream, c->fb.ids, -2, px);
@@ -760,6 +779,19 @@ int rt_set_counting(rt_context *c, int enable)
 {
     if (!c) return fail(RT_ERR_INVALID, "null context");
     c->counting = enable != 0;
+    return RT_OK;
+}
+
+// Undocumented diagnostic: wave-cycle totals per phase of the instrumented persistent kernel
+// (inner, triangle, shadow hand-over, shade, whole kernel), valid after a counting run.
+int rt_debug_phase_cycles(rt_context *c, uint64_t out[5])
+{
+    if (!c || !out) return fail(RT_ERR_INVALID, "null argument");
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    unsigned long long tmp[5];
+    RT_HIP_CHECK(hipMemcpyAsync(tmp, c->fb.counters + 16, sizeof tmp, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 5; i++) out[i] = tmp[i];
     return RT_OK;
 }
 

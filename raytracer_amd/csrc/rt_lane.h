@@ -39,6 +39,12 @@ enum : int32_t {
 
 constexpr int32_t kNoHit = 0x7fffffff;
 
+// ray_all calls as the reference makes them, and those actually traversed (the
+// camera ray of samples 1.. of a pixel-frame is answered from the lane's cache).
+struct RayCounts {
+    uint32_t calls, traversed;
+};
+
 struct Lane {
     int32_t mode;
     // pixel / frame
@@ -47,6 +53,8 @@ struct Lane {
     uint32_t rng, sample, bounce;
     f3 prim_d, total;
     int32_t primary_id;
+    float prim_t;         // closest hit of the camera ray, traced once per pixel-frame:
+    int32_t prim_best_id; // every sample of a frame starts on the same ray (raytracer_compute.wgsl:329-336)
     // path
     f3 color, light;
     bool spec;
@@ -73,13 +81,31 @@ RT_HD void lane_pop(Lane &L, Stack &stack)
     else L.cur = stack.pop();
 }
 
-// Starts ray_all for the lane's ray (L.o, L.d): spheres are tested here
-// (raytracer_compute.wgsl:19-24), triangles by the step functions.
+// Sphere part of ray_all (raytracer_compute.wgsl:19-24) for the lane's ray,
+// merged into L.tmax / L.best_id under the reference's selection rule.
+RT_HD void lane_test_spheres(const SceneView &sc, Lane &L, TestCounts *cnt)
+{
+    for (uint32_t i = 0; i < sc.n_spheres; i++) {
+        float tn;
+        float t = sphere_t(L.o, L.d, sc.spheres[4 * i], tn);
+        if (cnt) cnt->spheres++;
+        if (!(t > 0.0f)) continue;
+        if (L.anyhit) {
+            if (!(t > L.tmax)) { L.best_id = (int32_t)i; L.cur = kNoRoot; }
+        } else if (t < L.tmax || (t == L.tmax && (int32_t)i < L.best_id)) {
+            L.tmax = t;
+            L.best_id = (int32_t)i;
+        }
+    }
+}
+
+// Starts ray_all for the lane's ray (L.o, L.d).
 template <class Stack>
-RT_HD void lane_launch_ray(const SceneView &sc, Lane &L, Stack &stack, bool anyhit, float limit, uint32_t &n_rays,
+RT_HD void lane_launch_ray(const SceneView &sc, Lane &L, Stack &stack, bool anyhit, float limit, RayCounts &n_rays,
                            TestCounts *cnt)
 {
-    n_rays++;
+    n_rays.calls++;
+    n_rays.traversed++;
     L.anyhit = anyhit;
     L.tmax = anyhit ? limit : INFINITY;
     L.best_id = kNoHit;
@@ -88,18 +114,7 @@ RT_HD void lane_launch_ray(const SceneView &sc, Lane &L, Stack &stack, bool anyh
     L.cur = sc.root;
     if (all_nan(L.d)) L.cur = kNoRoot; // every test of the reference fails on a NaN direction
     else {
-        for (uint32_t i = 0; i < sc.n_spheres; i++) {
-            float tn;
-            float t = sphere_t(L.o, L.d, sc.spheres[4 * i], tn);
-            if (cnt) cnt->spheres++;
-            if (!(t > 0.0f)) continue;
-            if (anyhit) {
-                if (!(t > limit)) { L.best_id = (int32_t)i; L.cur = kNoRoot; }
-            } else if (t < L.tmax || (t == L.tmax && (int32_t)i < L.best_id)) {
-                L.tmax = t;
-                L.best_id = (int32_t)i;
-            }
-        }
+        lane_test_spheres(sc, L, cnt);
         L.rb = make_raybox(L.o, L.d);
     }
     if (L.cur == kNoRoot) L.mode = anyhit ? kLaneShadowDone : kLaneShadeClosest;
@@ -130,7 +145,7 @@ RT_HD void lane_step_triangle(const SceneView &sc, Lane &L, Stack &stack, TestCo
 {
     uint32_t code = (uint32_t)~L.cur;
     uint32_t first = code >> 3, left = code & 7u; // triangles after this one
-    const f4 *tr = sc.tri_isect + 3 * (size_t)first;
+    const f4 *tr = sc.tri_isect + kTriRecord * (size_t)first;
     f4 a = tr[0], b = tr[1], c = tr[2];
     float t = triangle_t(L.o, L.d, xyz(a), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x));
     if (cnt) cnt->tris++;
@@ -140,7 +155,7 @@ RT_HD void lane_step_triangle(const SceneView &sc, Lane &L, Stack &stack, TestCo
         int32_t id = (int32_t)(orig + sc.n_spheres);
         bool candidate = L.anyhit ? !(t > L.tmax) : (t < L.tmax || (t == L.tmax && id < L.best_id));
         if (candidate) {
-            f3 nrm = xyz(sc.tri_shade[3 * (size_t)orig]); // common.wgsl:202-207
+            f3 nrm = xyz(kTriRecord == 4 ? tr[3] : sc.tri_shade[3 * (size_t)orig]); // common.wgsl:202-207
             if (!(dot(nrm, L.d) > 0.0f)) {
                 L.best_id = id;
                 if (L.anyhit) stop = true;
@@ -153,10 +168,11 @@ RT_HD void lane_step_triangle(const SceneView &sc, Lane &L, Stack &stack, TestCo
     else lane_pop(L, stack);
 }
 
-// A path has ended with radiance L.light (raytracer_compute.wgsl:335-336).
-// Returns true when the lane must launch the camera ray again for its next
-// sample (L.o, L.d are set); false when the pixel is finished.
-RT_HD bool lane_end_path(const FrameParams &fp, Lane &L)
+// A path has ended with radiance L.light (raytracer_compute.wgsl:335-336): the
+// next sample starts on the same camera ray, whose ray_all result is already
+// known, so the lane goes straight back to kLaneShadeClosest; after the last
+// sample the pixel is finished.
+RT_HD void lane_end_path(const FrameParams &fp, Lane &L, RayCounts &n_rays)
 {
     L.total = add(L.total, L.light);
     L.sample++;
@@ -167,15 +183,20 @@ RT_HD bool lane_end_path(const FrameParams &fp, Lane &L)
         L.bounce = 0;
         L.o = fp.cam_pos;
         L.d = L.prim_d;
-        return true;
+        L.anyhit = false;
+        L.tmax = L.prim_t;
+        L.best_id = L.prim_best_id;
+        L.cur = kNoRoot;
+        L.mode = kLaneShadeClosest;
+        n_rays.calls++;
+    } else {
+        L.mode = kLanePixelDone;
     }
-    L.mode = kLanePixelDone;
-    return false;
 }
 
 // Seed, jitter, camera ray and the first path of a pixel (raytracer_compute.wgsl:293-336).
 template <class Stack>
-RT_HD void lane_begin_pixel(const SceneView &sc, const FrameParams &fp, Lane &L, Stack &stack, uint32_t &n_rays,
+RT_HD void lane_begin_pixel(const SceneView &sc, const FrameParams &fp, Lane &L, Stack &stack, RayCounts &n_rays,
                             TestCounts *cnt)
 {
     L.prim_d = primary_direction(fp, L.px, L.py, L.rng);
@@ -196,12 +217,16 @@ RT_HD f3 lane_pixel_color(const FrameParams &fp, const Lane &L) { return divs(L.
 
 // Lane in kLaneShadeClosest: consumes the closest-hit result.
 template <class Stack>
-RT_HD void lane_shade_closest(const SceneView &sc, const FrameParams &fp, Lane &L, Stack &stack, uint32_t &n_rays,
+RT_HD void lane_shade_closest(const SceneView &sc, const FrameParams &fp, Lane &L, Stack &stack, RayCounts &n_rays,
                               TestCounts *cnt)
 {
     int32_t id = (L.best_id == kNoHit) ? -1 : L.best_id;
     float t = L.tmax;
-    if (L.bounce == 0u && L.sample == 0u) L.primary_id = id;
+    if (L.bounce == 0u && L.sample == 0u) {
+        L.primary_id = id;
+        L.prim_t = L.tmax;
+        L.prim_best_id = L.best_id;
+    }
     bool end_path = false, launch = false, launch_anyhit = false;
     float launch_limit = 0.0f;
     if (id < 0) { // raytracer_compute.wgsl:198-202
@@ -239,25 +264,24 @@ RT_HD void lane_shade_closest(const SceneView &sc, const FrameParams &fp, Lane &
             else end_path = true;
         }
     }
-    if (end_path) launch = lane_end_path(fp, L);
     if (launch) lane_launch_ray(sc, L, stack, launch_anyhit, launch_limit, n_rays, cnt);
+    if (end_path) lane_end_path(fp, L, n_rays);
 }
 
 // Lane in kLaneShadowDone: consumes the shadow result (raytracer_compute.wgsl:219-224, :242).
 template <class Stack>
-RT_HD void lane_shadow_done(const SceneView &sc, const FrameParams &fp, Lane &L, Stack &stack, uint32_t &n_rays,
+RT_HD void lane_shadow_done(const SceneView &sc, const FrameParams &fp, Lane &L, Stack &stack, RayCounts &n_rays,
                             TestCounts *cnt)
 {
     if (L.best_id == kNoHit) L.light = add(L.light, L.nee);
     if (L.has_em) L.light = add(L.light, L.em);
-    bool launch = true;
     if (L.path_continues) {
         L.o = L.next_o;
         L.d = L.next_d;
+        lane_launch_ray(sc, L, stack, false, 0.0f, n_rays, cnt);
     } else {
-        launch = lane_end_path(fp, L);
+        lane_end_path(fp, L, n_rays);
     }
-    if (launch) lane_launch_ray(sc, L, stack, false, 0.0f, n_rays, cnt);
 }
 
 } // namespace rt

@@ -178,13 +178,14 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
     const uint32_t total_tiles = tiles_per_frame * n_frames;
     std::vector<uint16_t> batch((size_t)n_frames * W * H * 4);
     std::atomic<uint32_t> work{0};
-    std::atomic<uint64_t> rays{0};
+    std::atomic<uint64_t> rays{0}, traversed{0};
 
     auto wave = [&]() {
         rt::Lane L[64];
         HostStack st[64];
         for (auto &l : L) l.mode = rt::kLaneNeedUnit;
-        uint32_t n_rays = 0, pool_tile = 0, pool_next = 64;
+        rt::RayCounts n_rays = {0, 0};
+        uint32_t pool_tile = 0, pool_next = 64;
         bool exhausted = false;
         for (;;) {
             for (;;) {
@@ -249,7 +250,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
                 L[i].mode = rt::kLaneNeedUnit;
             }
         }
-        rays += n_rays;
+        rays += n_rays.calls; traversed += n_rays.traversed;
     };
     std::vector<std::thread> th;
     for (int i = 1; i < n_threads; i++) th.emplace_back(wave);
@@ -265,6 +266,6 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
             if (k + 1 == n_frames && frame_f16) std::memcpy(frame_f16 + 4 * p, src, 8);
         }
     }
-    if (counters) counters[0] += rays;
+    if (counters) { counters[0] += rays; counters[13] += traversed; }
     return 0;
 }

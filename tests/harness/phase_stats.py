@@ -13,8 +13,16 @@ ctx.set_counting(True)
 ctx.set_uniforms(S.pack_uniforms(sc.camera, 1, W, H, spp))
 ctx.render_frames(1, frames); ctx.sync()
 c = [int(x) for x in ctx.read_counters()]
-rays = c[0]
+rays = c[13]
 print({k: v for k, v in os.environ.items() if k.startswith("RT_")}, "ms/frame %.2f" % (ctx.last_render_ms() / frames))
 print("per ray: nodes %.2f tris %.2f spheres %.2f bounces %.3f" % (c[1] / rays, c[2] / rays, c[3] / rays, c[4] / rays))
 for nm, it, ln in (("inner", c[5], c[6]), ("tri", c[7], c[8]), ("shade", c[9], c[10]), ("sdone", c[11], c[12])):
     print("%-6s wave-iterations %d  (%.2f per ray-of-wave)  active lanes/iter %.1f (%.0f%%)" % (nm, it, it * 64 / rays, ln / max(it, 1), 100 * ln / max(it, 1) / 64))
+
+import ctypes as C, numpy as np
+out = np.zeros(5, np.uint64)
+fn = ctx.lib.rt_debug_phase_cycles; fn.argtypes = [C.c_void_p, C.c_void_p]; fn.restype = C.c_int
+assert fn(ctx.handle, out.ctypes.data_as(C.c_void_p)) == 0
+tot = float(out[4])
+print("wave-cycle shares: inner %.1f%% tri %.1f%% sdone %.1f%% shade %.1f%% other %.1f%%" % tuple(
+    [100 * float(out[i]) / tot for i in range(4)] + [100 * (tot - float(out[:4].sum())) / tot]))

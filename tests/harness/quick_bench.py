@@ -13,7 +13,7 @@ for k, name_ in enumerate(['SHADE', 'LEAF', 'BPC', 'BATCH', 'SDONE']):
 ctx.set_scene(S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles))
 ctx.set_uniforms(S.pack_uniforms(sc.camera, 1, W, H, spp))
 ctx.render_frames(1, 1); ctx.sync()
-c0 = ctx.read_counters()[0]
+c0 = ctx.read_counters()[13]
 t = time.time(); ctx.render_frames(2, frames); ctx.sync(); dt = time.time() - t
-c1 = ctx.read_counters()[0]
+c1 = ctx.read_counters()[13]
 print(name, W, H, frames, spp, 'mode', mode, {k: v for k, v in os.environ.items() if k.startswith('RT_')}, 'ms/frame %.3f' % (dt * 1e3 / frames), 'gpu ms %.3f' % ctx.last_render_ms(), 'Mrays/s %.1f' % ((c1 - c0) / dt / 1e6), ctx.scene_stats())

@@ -37,7 +37,7 @@ class HarnessRenderer:
         self.accum = np.zeros((3, height, width), np.float32)
         self.frame_f16 = np.zeros((height, width, 4), np.uint16)
         self.ids = np.zeros((height, width), np.int32)
-        self.counters = np.zeros(8, np.uint64)
+        self.counters = np.zeros(16, np.uint64)
         self.frame_index = 0
         self.L = lib()
 
