@@ -99,7 +99,9 @@ def main():
     rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
     device = 0 if rehearse else local_rank
     torch.cuda.set_device(device)
-    if world > 1:
+    # RT_BENCH_FORCE_DIST=1 runs the collective path even with one rank (smoke test of the RCCL calls)
+    use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         if rehearse:
             dist.init_process_group("gloo")
         else:
@@ -118,13 +120,13 @@ def main():
     K, W = args.steps, args.warmup
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         ctx.sync()
 
     own = ctx.owned_rows()
-    local_rows = torch.empty((3, own, WIDTH), dtype=torch.float32, device="cuda") if world > 1 else None
+    local_rows = torch.empty((3, own, WIDTH), dtype=torch.float32, device="cuda") if use_dist else None
 
     # warmup (frames 1..W*frames_per_step); the timed run then restarts at frame 1
     if W > 0:
@@ -135,7 +137,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     ctx.render_frames(1, K * frames_per_step)
-    if world > 1:
+    if use_dist:
         # combine: every rank contributes its rows; rank 0 assembles the image
         ctx.export_owned_rows(local_rows.data_ptr())
         ctx.sync()
@@ -170,15 +172,14 @@ def main():
             raise SystemExit("verification failed")
 
     t = torch.tensor([dt, float(rays), kernel_ms, float(ray_calls)], dtype=torch.float64, device="cpu" if rehearse else "cuda")
-    if world > 1:
+    if use_dist:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt, kernel_ms, rays, ray_calls = float(tmax[0]), float(tmax[2]), int(tsum[1]), int(tsum[3])
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     # roofline: algorithmic flops of the timed launches / HIP-event time of those launches
@@ -262,7 +263,7 @@ def main():
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

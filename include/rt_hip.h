@@ -52,7 +52,8 @@ typedef enum rt_tuning {
     RT_TUNE_LEAF_LANES = 1,    /* visit leaves once this many lanes of a wave wait at one (1..64)               */
     RT_TUNE_BLOCKS_PER_CU = 2, /* resident 256-thread blocks per CU; 0 = occupancy query                        */
     RT_TUNE_BATCH_FRAMES = 3,  /* frames traced per launch by rt_render_frames (>= 1)                           */
-    RT_TUNE_SHADOW_DONE_LANES = 4 /* finish shadow rays once this many lanes of a wave wait for it (1..64)      */
+    RT_TUNE_SHADOW_DONE_LANES = 4, /* finish shadow rays once this many lanes of a wave wait for it (1..64)     */
+    RT_TUNE_REFILL_LANES = 5   /* fetch new pixels once this many lanes of a wave are idle (1..64)              */
 } rt_tuning;
 
 /* Message of the last failure on the calling thread ("" if none). */

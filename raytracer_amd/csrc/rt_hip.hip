@@ -54,6 +54,9 @@ struct LdsStack {
     __device__ void push(int32_t v) { base[sp * BLOCK] = v; sp++; }
     __device__ int32_t pop() { sp--; return base[sp * BLOCK]; }
     __device__ bool empty() const { return sp == 0; }
+    __device__ int32_t peek() const { return base[(sp > 0 ? sp - 1 : 0) * BLOCK]; }
+    __device__ void poke(int32_t v) { base[sp * BLOCK] = v; }
+    __device__ void advance(int d) { sp += d; }
 };
 
 __device__ inline uint32_t wave_sum(uint32_t v)
@@ -139,9 +142,9 @@ __global__ __launch_bounds__(kBlock) void render_tiles_kernel(rt::SceneView sc, 
 // Kernel B: persistent waves.  Every lane runs the path tracer as the state
 // machine of rt_lane.h and always owns one ray (closest-hit or shadow), so the
 // lanes of a wave need not be at the same sample, bounce or ray kind:
-//   - a wave takes work in 8x8-pixel tiles from a global counter (one atomic
-//     per 64 pixel-frames) into a wave-local pool; lanes that finish a pixel
-//     draw the next one from the pool through a ballot + prefix count;
+//   - lanes that finish a pixel get the next one from a global counter of
+//     (frame, pixel) units: one atomic per wave for all its idle lanes, ranks
+//     by ballot + prefix count; units are numbered 8x8-tile-major;
 //   - traversal steps run while enough lanes are still traversing; when the
 //     share of traversing lanes drops below a threshold, the lanes whose ray is
 //     finished are shaded and given their next ray, then traversal resumes
@@ -157,6 +160,7 @@ struct SchedParams {
     int shade_num;    // shade when traversing lanes * 8 < active lanes * shade_num
     int leaf_lanes;   // visit leaves when at least this many lanes wait at one (or no lane is at an inner node)
     int sdone_lanes;  // finish shadow rays when at least this many lanes wait for it (or no lane is traversing)
+    int refill_lanes; // fetch new pixels when at least this many lanes are idle (or the whole wave is)
 };
 
 struct BatchParams {
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(kBlock, RT_MINW) void render_persistent_kernel(rt::
 
     const uint32_t tiles_x = (uint32_t)(fp.width + 7) / 8u, tiles_y = (uint32_t)(local_rows + 7) / 8u;
     const uint32_t tiles_per_frame = tiles_x * tiles_y;
-    const uint32_t total_tiles = tiles_per_frame * bp.n_frames;
+    const uint32_t total_units = tiles_per_frame * bp.n_frames * 64u;
 
     rt::Lane L;
     L.mode = rt::kLaneNeedUnit;
@@ -190,8 +194,7 @@ __global__ __launch_bounds__(kBlock, RT_MINW) void render_persistent_kernel(rt::
              ph_sdone_it = 0, ph_sdone_ln = 0; // COUNT only
     unsigned long long tc_inner = 0, tc_tri = 0, tc_sdone = 0, tc_shade = 0, tc_total = 0, tc0 = 0, tc_begin = 0; // COUNT only: wave cycles per phase
     if (COUNT) tc_begin = clock64();
-    uint32_t pool_tile = 0, pool_next = 64; // wave-uniform: current tile and next unused slot in it
-    bool exhausted = false;                 // wave-uniform: the global counter has run out
+    bool exhausted = false; // wave-uniform: the global counter has run out
 
     for (;;) {
         // ---- store finished pixels -----------------------------------------------------------
@@ -212,46 +215,54 @@ __global__ __launch_bounds__(kBlock, RT_MINW) void render_persistent_kernel(rt::
         }
 
         // ---- hand out pixels to idle lanes ------------------------------------------------
+        // Units are numbered tile-major (64 consecutive units = one 8x8 tile), so lanes
+        // that refill together get neighbouring pixels.  A wave takes exactly as many
+        // units as it has idle lanes (one atomic for all of them), once enough lanes
+        // are idle or nothing else is left to do.
         for (;;) {
             unsigned long long need = __ballot(L.mode == rt::kLaneNeedUnit);
             if (need == 0ull) break;
-            if (pool_next >= 64u) {
-                if (exhausted) {
-                    if (L.mode == rt::kLaneNeedUnit) L.mode = rt::kLaneDead;
-                    break;
-                }
-                unsigned int tkt = 0;
-                if (lane == 0) tkt = atomicAdd(work_counter, 1u);
-                tkt = (unsigned int)__builtin_amdgcn_readfirstlane((int)tkt);
-                if (tkt >= total_tiles) { exhausted = true; continue; }
-                pool_tile = tkt;
-                pool_next = 0;
-            }
-            uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
             uint32_t n_need = (uint32_t)__popcll(need);
-            if (L.mode == rt::kLaneNeedUnit && pool_next + rank < 64u) {
-                uint32_t slot = pool_next + rank;
-                uint32_t frame_k = pool_tile / tiles_per_frame, tile = pool_tile % tiles_per_frame;
-                int px = (int)((tile % tiles_x) * 8u + (slot & 7u));
-                int ly = (int)((tile / tiles_x) * 8u + (slot >> 3));
-                int py = stripe_global_row(sm, ly);
-                if (px < fp.width && ly < local_rows && py < fp.height) {
-                    L.px = px;
-                    L.py = py;
-                    L.frame_k = frame_k;
-                    if (fp.max_bounces == 0u) {
-                        // the bounce loop never runs: zero radiance, no rays (raytracer_compute.wgsl:196)
-                        L.total = rt::mk3(0.0f, 0.0f, 0.0f);
-                        L.primary_id = -1;
-                        L.mode = rt::kLanePixelDone;
-                    } else {
-                        rt::FrameParams f = fp;
-                        if (!FUSED) f.seed_add = (uint32_t)(float)(bp.first_frame + frame_k) * 12345u;
-                        rt::lane_begin_pixel(sc, f, L, stack, n_rays, cp);
+            if (exhausted) {
+                if (L.mode == rt::kLaneNeedUnit) L.mode = rt::kLaneDead;
+                break;
+            }
+            bool any_busy = __ballot(L.mode != rt::kLaneNeedUnit && L.mode != rt::kLaneDead) != 0ull;
+            if (any_busy && n_need < (uint32_t)sched.refill_lanes) break;
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(work_counter, n_need);
+            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+            if (base + n_need >= total_units) exhausted = true;
+            uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            if (L.mode == rt::kLaneNeedUnit) {
+                uint32_t unit = base + rank;
+                if (unit >= total_units) {
+                    L.mode = rt::kLaneDead;
+                } else {
+                    uint32_t tile_all = unit >> 6, slot = unit & 63u;
+                    uint32_t frame_k = tile_all / tiles_per_frame, tile = tile_all % tiles_per_frame;
+                    int px = (int)((tile % tiles_x) * 8u + (slot & 7u));
+                    int ly = (int)((tile / tiles_x) * 8u + (slot >> 3));
+                    int py = stripe_global_row(sm, ly);
+                    if (px < fp.width && ly < local_rows && py < fp.height) {
+                        L.px = px;
+                        L.py = py;
+                        L.frame_k = frame_k;
+                        if (fp.max_bounces == 0u) {
+                            // the bounce loop never runs: zero radiance, no rays (raytracer_compute.wgsl:196)
+                            L.total = rt::mk3(0.0f, 0.0f, 0.0f);
+                            L.primary_id = -1;
+                            L.mode = rt::kLanePixelDone;
+                        } else {
+                            rt::FrameParams f = fp;
+                            if (!FUSED) f.seed_add = (uint32_t)(float)(bp.first_frame + frame_k) * 12345u;
+                            rt::lane_begin_pixel(sc, f, L, stack, n_rays, cp);
+                        }
                     }
                 }
             }
-            pool_next += n_need < 64u - pool_next ? n_need : 64u - pool_next;
+            if (!any_busy) continue; // padding pixels of edge tiles leave lanes idle: ask again
+            break;
         }
         if (__ballot(L.mode != rt::kLaneDead) == 0ull) break;
 
@@ -431,7 +442,7 @@ struct rt_context {
     uint32_t work_used = 0;
     uint2 *d_batch = nullptr;       // frame colours of a batch
     size_t batch_capacity = 0;      // in frames
-    int tune_shade_num = 2, tune_leaf_lanes = 8, tune_blocks_per_cu = 0, tune_batch = 16, tune_sdone_lanes = 2;
+    int tune_shade_num = 2, tune_leaf_lanes = 12, tune_blocks_per_cu = 0, tune_batch = 16, tune_sdone_lanes = 2, tune_refill_lanes = 4;
 
     void free_scene()
     {
@@ -483,7 +494,7 @@ int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchPar
     uint64_t tiles = (uint64_t)((c->width + 7) / 8) * (uint64_t)((c->local_rows + 7) / 8) * bp.n_frames;
     uint64_t blocks = std::min<uint64_t>((uint64_t)c->n_cus * per_cu, (tiles + 3) / 4);
     if (blocks == 0) return RT_OK;
-    SchedParams sched{c->tune_shade_num, c->tune_leaf_lanes, c->tune_sdone_lanes};
+    SchedParams sched{c->tune_shade_num, c->tune_leaf_lanes, c->tune_sdone_lanes, c->tune_refill_lanes};
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, c->view, fp, c->sm, c->local_rows, c->fb,
                        bp, counter, sched);
     RT_HIP_CHECK(hipGetLastError());
@@ -507,7 +518,7 @@ int launch_persistent(rt_context *c, uint32_t first, uint32_t n)
     uint64_t tiles_per_frame = (uint64_t)((c->width + 7) / 8) * (uint64_t)((c->local_rows + 7) / 8);
     uint32_t max_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->tune_batch,
                                                       std::min<uint64_t>(kBatchBytesCap / (local_px * sizeof(uint2)),
-                                                                         0x7fffffffull / tiles_per_frame)));
+                                                                         0x7fffffffull / (tiles_per_frame * 64))));
     uint32_t done = 0;
     while (done < n) {
         uint32_t b = std::min(max_batch, n - done);
@@ -686,6 +697,7 @@ int rt_set_tuning(rt_context *c, int key, int value)
     case RT_TUNE_LEAF_LANES: if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "leaf_lanes out of range"); c->tune_leaf_lanes = value; break;
     case RT_TUNE_BLOCKS_PER_CU: if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "blocks_per_cu out of range"); c->tune_blocks_per_cu = value; break;
     case RT_TUNE_BATCH_FRAMES: if (value < 1 || value > 4096) return fail(RT_ERR_INVALID, "batch_frames out of range"); c->tune_batch = value; break;
+    case RT_TUNE_REFILL_LANES: if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "refill_lanes out of range"); c->tune_refill_lanes = value; break;
     case RT_TUNE_SHADOW_DONE_LANES: if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "shadow_done_lanes out of range"); c->tune_sdone_lanes = value; break;
     default: return fail(RT_ERR_INVALID, "unknown tuning key");
     }

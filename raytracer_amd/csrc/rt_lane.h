@@ -26,6 +26,13 @@
 
 #include "rt_core.h"
 
+#ifndef RT_FLAT_INNER
+#define RT_FLAT_INNER 0
+#endif
+#ifndef RT_FLAT_TRI
+#define RT_FLAT_TRI 0
+#endif
+
 namespace rt {
 
 enum : int32_t {
@@ -120,6 +127,7 @@ RT_HD void lane_launch_ray(const SceneView &sc, Lane &L, Stack &stack, bool anyh
     if (L.cur == kNoRoot) L.mode = anyhit ? kLaneShadowDone : kLaneShadeClosest;
 }
 
+#if !RT_FLAT_INNER
 template <class Stack>
 RT_HD void lane_step_inner(const SceneView &sc, Lane &L, Stack &stack, TestCounts *cnt)
 {
@@ -138,6 +146,34 @@ RT_HD void lane_step_inner(const SceneView &sc, Lane &L, Stack &stack, TestCount
     else if (h1) L.cur = c1;
     else lane_pop(L, stack);
 }
+#else
+// One node visit, written without branches: the far child is stored above the
+// stack top whether or not it is needed (sp only moves when both children are
+// hit) and the stack top is read before it is known to be needed, so that the
+// LDS latency overlaps the node fetch.  `Stack` must have room for one entry
+// above the deepest push.
+template <class Stack>
+RT_HD void lane_step_inner(const SceneView &sc, Lane &L, Stack &stack, TestCounts *cnt)
+{
+    const f4 *n = sc.nodes + 4 * (size_t)L.cur;
+    int32_t top = stack.peek();
+    f4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+    float tn0, tn1;
+    bool h0 = slab(L.rb, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, L.tmax, tn0);
+    bool h1 = slab(L.rb, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, L.tmax, tn1);
+    if (cnt) cnt->boxes++;
+    int32_t c0 = (int32_t)f2u(q3.x), c1 = (int32_t)f2u(q3.y);
+    bool both = h0 & h1, none = !(h0 | h1);
+    bool first0 = h0 & !(h1 & (tn1 < tn0)); // child 0 next: only it is hit, or both and it is not farther
+    int32_t near = first0 ? c0 : c1, far = first0 ? c1 : c0;
+    stack.poke(far);
+    bool empty = stack.empty();
+    stack.advance(both ? 1 : ((none & !empty) ? -1 : 0));
+    L.cur = none ? (empty ? kNoRoot : top) : near;
+    if (none & empty) L.mode = L.anyhit ? kLaneShadowDone : kLaneShadeClosest;
+}
+
+#endif
 
 // Tests the first triangle of the leaf L.cur and shrinks the leaf by it.
 template <class Stack>
@@ -147,7 +183,11 @@ RT_HD void lane_step_triangle(const SceneView &sc, Lane &L, Stack &stack, TestCo
     uint32_t first = code >> 3, left = code & 7u; // triangles after this one
     const f4 *tr = sc.tri_isect + kTriRecord * (size_t)first;
     f4 a = tr[0], b = tr[1], c = tr[2];
+#if RT_FLAT_TRI
+    float t = triangle_t_flat(L.o, L.d, xyz(a), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x));
+#else
     float t = triangle_t(L.o, L.d, xyz(a), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x));
+#endif
     if (cnt) cnt->tris++;
     bool stop = false;
     if (t > 0.0f) {

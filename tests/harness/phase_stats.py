@@ -6,7 +6,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "suzanne"
 W, H, spp, frames = 1920, 1080, 16, 2
 sc = S.load_scene(S.scene_path(name))
 ctx = capi.Context(W, H)
-for k, n in enumerate(["SHADE", "LEAF", "BPC", "BATCH", "SDONE"]):
+for k, n in enumerate(["SHADE", "LEAF", "BPC", "BATCH", "SDONE", "REFILL"]):
     if "RT_" + n in os.environ: ctx.set_tuning(k, int(os.environ["RT_" + n]))
 ctx.set_scene(S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles))
 ctx.set_counting(True)

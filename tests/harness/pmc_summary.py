@@ -7,7 +7,7 @@ for f in glob.glob(root + '/kt/*/*_kernel_stats.csv'):
         out.setdefault('kernel_stats', []).append({k: r[k] for k in ('Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage')})
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 meta = {}
-for f in glob.glob(root + '/pmc*/*/*_counter_collection.csv'):
+for f in glob.glob(root + '/*/*/*_counter_collection.csv'):
     disp = collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']

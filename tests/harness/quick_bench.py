@@ -8,7 +8,7 @@ sc = S.load_scene(S.scene_path(name))
 ctx = capi.Context(W, H)
 ctx.set_mode(mode)
 import os
-for k, name_ in enumerate(['SHADE', 'LEAF', 'BPC', 'BATCH', 'SDONE']):
+for k, name_ in enumerate(['SHADE', 'LEAF', 'BPC', 'BATCH', 'SDONE', 'REFILL']):
     if 'RT_' + name_ in os.environ: ctx.set_tuning(k, int(os.environ['RT_' + name_]))
 ctx.set_scene(S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles))
 ctx.set_uniforms(S.pack_uniforms(sc.camera, 1, W, H, spp))

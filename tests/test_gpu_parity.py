@@ -104,3 +104,37 @@ def test_triangle_test_counter_wraps_like_u32(scenes):
     assert ctx.take_triangle_tests() == (rays * 982) % 2**32
     assert ctx.take_triangle_tests() == 0
     ctx.close()
+
+
+def test_heightfield_8k_triangles_vs_oracle():
+    """A mesh the reference scenes do not have: 8,206 triangles, deeper tree."""
+    from tests.synth import heightfield_scene
+
+    run_pair(heightfield_scene(64), 96, 54, 1, 2, capi.RT_MODE_BVH)
+
+
+def test_heightfield_131k_triangles_bvh_vs_brute_force_on_gpu():
+    """131,086 triangles: too slow for the CPU oracle, so the BVH kernels are compared with the GPU's own
+    brute-force mode (the reference's ray_all loop), which the other tests tie to the oracle."""
+    from tests.synth import heightfield_scene
+
+    scene = heightfield_scene(256)
+    sp, tr = S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles)
+    width, height, spp = 64, 36, 2
+    out = {}
+    for mode in (capi.RT_MODE_BRUTE_FORCE, capi.RT_MODE_BVH, capi.RT_MODE_BVH_TILES):
+        ctx = capi.Context(width, height)
+        ctx.set_mode(mode)
+        ctx.set_scene(sp, tr)
+        if mode == capi.RT_MODE_BVH:
+            assert ctx.scene_stats()["max_depth"] >= 16   # exercises the 32-entry traversal stack
+        ctx.set_uniforms(S.pack_uniforms(scene.camera, 1, width, height, spp))
+        ctx.render_frames(1, 2)
+        out[mode] = (ctx.read_primary_ids(), ctx.read_frame_f16(), ctx.read_accum(), int(ctx.read_counters()[0]))
+        ctx.close()
+    ref = out[capi.RT_MODE_BRUTE_FORCE]
+    for mode in (capi.RT_MODE_BVH, capi.RT_MODE_BVH_TILES):
+        assert np.array_equal(out[mode][0], ref[0])
+        assert _f16_equal(out[mode][1], ref[1])
+        assert np.array_equal(out[mode][2], ref[2])
+        assert out[mode][3] == ref[3]
