@@ -36,7 +36,7 @@ WIDTH, HEIGHT, SPP, MAX_BOUNCES = 1920, 1080, 16, 6
 PEAK_FP32_TFLOPS = 157.3  # MI355X FP32 vector peak (packed FMA), chip-level spec
 # algorithmic flop prices per test / per bounce ("Roofline accounting")
 F_BOX, F_TRI, F_SPH, F_SHADE = 24, 52, 31, 160
-BATCH_FRAMES = 16  # the library's default frames per launch (RT_TUNE_BATCH_FRAMES)
+BATCH_FRAMES = 16  # frames per launch the library chooses for a full 1920x1080 image
 
 
 def parse_args():
@@ -199,7 +199,8 @@ def main():
     flops_per_ray = (2 * c_boxpairs * F_BOX + c_tris * F_TRI + c_sph * F_SPH + c_bounces * F_SHADE) / c_rays
     brute_flops_per_ray = F_SPH * len(spheres) + F_TRI * len(tris)
     frames = K * frames_per_step
-    launches = (frames + BATCH_FRAMES - 1) // BATCH_FRAMES   # rt_render_frames traces up to BATCH_FRAMES frames per launch
+    batch = BATCH_FRAMES * world    # frames per launch: the library keeps about 16 x 1920 x 1080 units per launch
+    launches = (frames + batch - 1) // batch
     rays_per_launch = rays / world / launches
     launch_ms = kernel_ms / launches
     achieved = flops_per_ray * rays_per_launch / (launch_ms * 1e-3) / 1e12
@@ -245,7 +246,7 @@ def main():
             "frac": achieved / PEAK_FP32_TFLOPS,
             "traffic": traffic,
             "kernel": "render_persistent_kernel (path trace of up to %d frames per launch; the ordered accumulate kernel "
-                      "that follows it is included in the timing and is < 0.1%% of it)" % BATCH_FRAMES,
+                      "that follows it is included in the timing and is < 0.1%% of it)" % batch,
             "launches": launches,
             "kernel_ms_per_launch": launch_ms,
             "flops_per_ray": flops_per_ray,

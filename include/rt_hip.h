@@ -51,9 +51,11 @@ typedef enum rt_tuning {
     RT_TUNE_SHADE_NUM = 0,     /* shade finished lanes when traversing lanes * 8 < active lanes * value (0..8) */
     RT_TUNE_LEAF_LANES = 1,    /* visit leaves once this many lanes of a wave wait at one (1..64)               */
     RT_TUNE_BLOCKS_PER_CU = 2, /* resident 256-thread blocks per CU; 0 = occupancy query                        */
-    RT_TUNE_BATCH_FRAMES = 3,  /* frames traced per launch by rt_render_frames (>= 1)                           */
+    RT_TUNE_BATCH_FRAMES = 3,  /* frames traced per launch by rt_render_frames; 0 = automatic (default)        */
     RT_TUNE_SHADOW_DONE_LANES = 4, /* finish shadow rays once this many lanes of a wave wait for it (1..64)     */
-    RT_TUNE_REFILL_LANES = 5   /* fetch new pixels once this many lanes of a wave are idle (1..64)              */
+    RT_TUNE_REFILL_LANES = 5,  /* fetch new pixels once this many lanes of a wave are idle (1..64)              */
+    RT_TUNE_MAX_LEAF = 6,      /* triangles per BVH leaf, 1..8; takes effect at the next rt_set_scene           */
+    RT_TUNE_TRI_COST_X10 = 7   /* SAH cost of a triangle test relative to a node visit, in tenths; next rt_set_scene */
 } rt_tuning;
 
 /* Message of the last failure on the calling thread ("" if none). */

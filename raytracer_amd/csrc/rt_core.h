@@ -107,6 +107,9 @@ RT_HD float luminance(f3 c) { return dot(c, mk3(0.2126f, 0.7152f, 0.0722f)); }
 // nodes      4 x f4 per node: child boxes (lo0,hi0,lo1,hi1 packed) + two child
 //            links.  A link >= 0 is a node index; a link < 0 encodes a leaf as
 //            ~((first << 3) | (count - 1)) over tri_isect.
+// nodes4     8 x f4 per 4-wide node (persistent kernel): lo.x[4] lo.y[4] lo.z[4]
+//            hi.x[4] hi.y[4] hi.z[4] links[4] pad; same link encoding; unused
+//            slots (2 and 3 only) carry the link kNoRoot.
 // tri_isect  4 x f4 per triangle in leaf order:
 //            (v0.xyz, e01.x) (e01.yz, e02.xy) (e02.z, bits(original index), 0, 0)
 //            (unit normal.xyz, 0) -- a copy of tri_shade's, so that the back-face
@@ -123,6 +126,7 @@ RT_HD float luminance(f3 c) { return dot(c, mk3(0.2126f, 0.7152f, 0.0722f)); }
 // ---------------------------------------------------------------------------
 struct SceneView {
     const f4 *nodes;
+    const f4 *nodes4;
     const f4 *tri_isect;
     const f4 *tri_shade;
     const f4 *tri_raw;
@@ -134,6 +138,7 @@ struct SceneView {
     uint32_t n_lights_pass1; // entries counted by the first scan (strength not <= 0)
     float total_power;
     int32_t root;            // root link (leaf-encoded when the tree is one leaf); 0x7fffffff if no triangles
+    int32_t root4;           // the same for the 4-wide tree
 };
 
 constexpr int32_t kNoRoot = 0x7fffffff;

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kBlock, RT_MINW) void render_persistent_kernel(rt::
 
             bool inner = L.mode == rt::kLaneTraverse && rt::link_is_inner(L.cur);
             if (COUNT) { int n_in = __popcll(__ballot(inner)); if (n_in) { ph_inner_it++; ph_inner_ln += n_in; } tc0 = clock64(); }
-            if (inner) rt::lane_step_inner(sc, L, stack, cp);
+            if (inner) rt::lane_step_node(sc, L, stack, cp);
             if (COUNT) tc_inner += clock64() - tc0;
 
             bool leaf = L.mode == rt::kLaneTraverse && rt::link_is_leaf(L.cur);
@@ -424,7 +424,7 @@ struct rt_context {
     // scene
     rt::BuiltScene host_scene;
     rt::SceneView view{};
-    rt::f4 *d_nodes = nullptr, *d_tri_isect = nullptr, *d_tri_shade = nullptr, *d_tri_raw = nullptr, *d_spheres = nullptr,
+    rt::f4 *d_nodes = nullptr, *d_nodes4 = nullptr, *d_tri_isect = nullptr, *d_tri_shade = nullptr, *d_tri_raw = nullptr, *d_spheres = nullptr,
            *d_lights = nullptr;
     bool has_scene = false;
     size_t scene_bytes = 0;
@@ -442,12 +442,12 @@ struct rt_context {
     uint32_t work_used = 0;
     uint2 *d_batch = nullptr;       // frame colours of a batch
     size_t batch_capacity = 0;      // in frames
-    int tune_shade_num = 2, tune_leaf_lanes = 12, tune_blocks_per_cu = 0, tune_batch = 16, tune_sdone_lanes = 2, tune_refill_lanes = 4;
+    int tune_shade_num = 2, tune_leaf_lanes = 12, tune_blocks_per_cu = 0, tune_batch = 0, tune_sdone_lanes = 2, tune_refill_lanes = 4, tune_max_leaf = 4, tune_tri_cost_x10 = 12;
 
     void free_scene()
     {
-        for (rt::f4 *p : {d_nodes, d_tri_isect, d_tri_shade, d_tri_raw, d_spheres, d_lights}) (void)hipFree(p);
-        d_nodes = d_tri_isect = d_tri_shade = d_tri_raw = d_spheres = d_lights = nullptr;
+        for (rt::f4 *p : {d_nodes, d_nodes4, d_tri_isect, d_tri_shade, d_tri_raw, d_spheres, d_lights}) (void)hipFree(p);
+        d_nodes = d_nodes4 = d_tri_isect = d_tri_shade = d_tri_raw = d_spheres = d_lights = nullptr;
         has_scene = false;
     }
 };
@@ -456,6 +456,7 @@ namespace {
 
 constexpr uint32_t kWorkCounters = 4096;
 constexpr size_t kBatchBytesCap = (size_t)1 << 30;
+constexpr uint64_t kUnitsPerLaunch = 16ull * 1920 * 1080;
 
 int launch_tiles(rt_context *c, const rt::FrameParams &fp)
 {
@@ -504,10 +505,12 @@ int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchPar
 template <bool COUNT, bool FUSED>
 int launch_persistent_d(rt_context *c, const rt::FrameParams &fp, const BatchParams &bp, unsigned int *counter)
 {
-    uint32_t depth = c->host_scene.max_depth;
-    if (depth < 16) return launch_persistent_t<16, COUNT, FUSED>(c, fp, bp, counter);
-    if (depth < 32) return launch_persistent_t<32, COUNT, FUSED>(c, fp, bp, counter);
-    return launch_persistent_t<64, COUNT, FUSED>(c, fp, bp, counter);
+    // entries the traversal stack must hold (one spare for the binary tree's branch-free variant)
+    uint32_t depth = rt::kWideBvh ? c->host_scene.max_stack4 : c->host_scene.max_depth + 1;
+    if (depth <= 16) return launch_persistent_t<16, COUNT, FUSED>(c, fp, bp, counter);
+    if (depth <= 32) return launch_persistent_t<32, COUNT, FUSED>(c, fp, bp, counter);
+    if (depth <= 64) return launch_persistent_t<64, COUNT, FUSED>(c, fp, bp, counter);
+    return fail(RT_ERR_UNSUPPORTED, "acceleration structure too deep for the traversal stack");
 }
 
 // Frames first .. first + n - 1 through the persistent kernel, in batches.
@@ -516,7 +519,13 @@ int launch_persistent(rt_context *c, uint32_t first, uint32_t n)
     size_t local_px = (size_t)c->local_rows * c->width;
     if (local_px == 0 || n == 0) return RT_OK;
     uint64_t tiles_per_frame = (uint64_t)((c->width + 7) / 8) * (uint64_t)((c->local_rows + 7) / 8);
-    uint32_t max_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->tune_batch,
+    // Frames per launch.  Every launch ends with a tail in which lanes finish their last pixel
+    // (16 serial samples, a few ms) while others idle, so launches should be long: by default
+    // about kUnitsPerLaunch (frame, pixel) units, i.e. 16 frames of a 1920x1080 image, more
+    // frames when the context owns fewer pixels.  Bounded by the batch buffer size.
+    uint64_t want = c->tune_batch > 0 ? (uint64_t)c->tune_batch
+                                      : std::max<uint64_t>(1, (kUnitsPerLaunch + local_px / 2) / local_px);
+    uint32_t max_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want,
                                                       std::min<uint64_t>(kBatchBytesCap / (local_px * sizeof(uint2)),
                                                                          0x7fffffffull / (tiles_per_frame * 64))));
     uint32_t done = 0;
@@ -640,20 +649,22 @@ int rt_set_scene(rt_context *c, const void *spheres, uint32_t n_spheres, const v
     RT_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->free_scene();
     rt::BuildOptions opt;
+    opt.max_leaf = (uint32_t)c->tune_max_leaf;
+    opt.triangle_cost = 0.1f * (float)c->tune_tri_cost_x10;
     rt::build_scene(spheres, n_spheres, triangles, n_triangles, opt, c->host_scene);
     if (c->host_scene.max_depth >= 64) return fail(RT_ERR_UNSUPPORTED, "acceleration structure too deep");
     const rt::BuiltScene &hs = c->host_scene;
     int rc;
-    if ((rc = upload(hs.nodes, &c->d_nodes, c->stream)) || (rc = upload(hs.tri_isect, &c->d_tri_isect, c->stream)) ||
+    if ((rc = upload(hs.nodes, &c->d_nodes, c->stream)) || (rc = upload(hs.nodes4, &c->d_nodes4, c->stream)) || (rc = upload(hs.tri_isect, &c->d_tri_isect, c->stream)) ||
         (rc = upload(hs.tri_shade, &c->d_tri_shade, c->stream)) || (rc = upload(hs.tri_raw, &c->d_tri_raw, c->stream)) ||
         (rc = upload(hs.spheres, &c->d_spheres, c->stream)) || (rc = upload(hs.lights, &c->d_lights, c->stream))) {
         c->free_scene();
         return rc;
     }
     RT_HIP_CHECK(hipStreamSynchronize(c->stream));
-    c->scene_bytes = (hs.nodes.size() + hs.tri_isect.size() + hs.tri_shade.size() + hs.spheres.size() + hs.lights.size()) * sizeof(rt::f4);
+    c->scene_bytes = (hs.nodes.size() + hs.nodes4.size() + hs.tri_isect.size() + hs.tri_shade.size() + hs.spheres.size() + hs.lights.size()) * sizeof(rt::f4);
     rt::SceneView &v = c->view;
-    v.nodes = c->d_nodes; v.tri_isect = c->d_tri_isect; v.tri_shade = c->d_tri_shade; v.tri_raw = c->d_tri_raw;
+    v.nodes = c->d_nodes; v.nodes4 = c->d_nodes4; v.root4 = hs.root4; v.tri_isect = c->d_tri_isect; v.tri_shade = c->d_tri_shade; v.tri_raw = c->d_tri_raw;
     v.spheres = c->d_spheres; v.lights = c->d_lights;
     v.n_spheres = hs.n_spheres; v.n_tris = hs.n_tris; v.n_lights = hs.n_lights; v.n_lights_pass1 = hs.n_lights_pass1;
     v.total_power = hs.total_power; v.root = hs.root;
@@ -696,7 +707,9 @@ int rt_set_tuning(rt_context *c, int key, int value)
     case RT_TUNE_SHADE_NUM: if (value < 0 || value > 8) return fail(RT_ERR_INVALID, "shade_num out of range"); c->tune_shade_num = value; break;
     case RT_TUNE_LEAF_LANES: if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "leaf_lanes out of range"); c->tune_leaf_lanes = value; break;
     case RT_TUNE_BLOCKS_PER_CU: if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "blocks_per_cu out of range"); c->tune_blocks_per_cu = value; break;
-    case RT_TUNE_BATCH_FRAMES: if (value < 1 || value > 4096) return fail(RT_ERR_INVALID, "batch_frames out of range"); c->tune_batch = value; break;
+    case RT_TUNE_BATCH_FRAMES: if (value < 0 || value > 4096) return fail(RT_ERR_INVALID, "batch_frames out of range"); c->tune_batch = value; break;
+    case RT_TUNE_MAX_LEAF: if (value < 1 || value > 8) return fail(RT_ERR_INVALID, "max_leaf out of range"); c->tune_max_leaf = value; break;
+    case RT_TUNE_TRI_COST_X10: if (value < 1 || value > 1000) return fail(RT_ERR_INVALID, "tri_cost out of range"); c->tune_tri_cost_x10 = value; break;
     case RT_TUNE_REFILL_LANES: if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "refill_lanes out of range"); c->tune_refill_lanes = value; break;
     case RT_TUNE_SHADOW_DONE_LANES: if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "shadow_done_lanes out of range"); c->tune_sdone_lanes = value; break;
     default: return fail(RT_ERR_INVALID, "unknown tuning key");

@@ -26,6 +26,9 @@
 
 #include "rt_core.h"
 
+#ifndef RT_WIDE_BVH
+#define RT_WIDE_BVH 1 // the lane state machine traverses the 4-wide tree (0: the binary tree)
+#endif
 #ifndef RT_FLAT_INNER
 #define RT_FLAT_INNER 0
 #endif
@@ -45,6 +48,7 @@ enum : int32_t {
 };
 
 constexpr int32_t kNoHit = 0x7fffffff;
+constexpr bool kWideBvh = RT_WIDE_BVH != 0;
 
 // ray_all calls as the reference makes them, and those actually traversed (the
 // camera ray of samples 1.. of a pixel-frame is answered from the lane's cache).
@@ -118,7 +122,7 @@ RT_HD void lane_launch_ray(const SceneView &sc, Lane &L, Stack &stack, bool anyh
     L.best_id = kNoHit;
     L.mode = kLaneTraverse;
     stack.reset();
-    L.cur = sc.root;
+    L.cur = kWideBvh ? sc.root4 : sc.root;
     if (all_nan(L.d)) L.cur = kNoRoot; // every test of the reference fails on a NaN direction
     else {
         lane_test_spheres(sc, L, cnt);
@@ -174,6 +178,46 @@ RT_HD void lane_step_inner(const SceneView &sc, Lane &L, Stack &stack, TestCount
 }
 
 #endif
+
+// One visit of a 4-wide node: four slab tests, the nearest hit child is visited
+// next and the other hit children go on the stack (unsorted: the order only
+// affects how much is culled later, never the result).
+template <class Stack>
+RT_HD void lane_step_inner4(const SceneView &sc, Lane &L, Stack &stack, TestCounts *cnt)
+{
+    const f4 *n = sc.nodes4 + 8 * (size_t)L.cur;
+    f4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], lk = n[6];
+    float t0, t1, t2, t3;
+    int32_t c0 = (int32_t)f2u(lk.x), c1 = (int32_t)f2u(lk.y), c2 = (int32_t)f2u(lk.z), c3 = (int32_t)f2u(lk.w);
+    // children 0 and 1 always exist; an unused slot (link kNoRoot) is never a hit whatever its box says
+    bool h0 = slab(L.rb, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, L.tmax, t0);
+    bool h1 = slab(L.rb, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, L.tmax, t1);
+    bool h2 = slab(L.rb, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, L.tmax, t2) & (c2 != kNoRoot);
+    bool h3 = slab(L.rb, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, L.tmax, t3) & (c3 != kNoRoot);
+    if (cnt) cnt->boxes += 2; // counted in box pairs
+    // nearest hit child
+    float tb = INFINITY;
+    int32_t next = kNoRoot;
+    int which = -1;
+    if (h0) { tb = t0; next = c0; which = 0; }
+    if (h1 && (which < 0 || t1 < tb)) { tb = t1; next = c1; which = 1; }
+    if (h2 && (which < 0 || t2 < tb)) { tb = t2; next = c2; which = 2; }
+    if (h3 && (which < 0 || t3 < tb)) { tb = t3; next = c3; which = 3; }
+    if (which < 0) { lane_pop(L, stack); return; }
+    if (h0 && which != 0) stack.push(c0);
+    if (h1 && which != 1) stack.push(c1);
+    if (h2 && which != 2) stack.push(c2);
+    if (h3 && which != 3) stack.push(c3);
+    L.cur = next;
+}
+
+// The node visit of whichever tree the lanes traverse.
+template <class Stack>
+RT_HD void lane_step_node(const SceneView &sc, Lane &L, Stack &stack, TestCounts *cnt)
+{
+    if (kWideBvh) lane_step_inner4(sc, L, stack, cnt);
+    else lane_step_inner(sc, L, stack, cnt);
+}
 
 // Tests the first triangle of the leaf L.cur and shrinks the leaf by it.
 template <class Stack>

@@ -305,6 +305,78 @@ void build_scene(const void *spheres, uint32_t n_spheres, const void *triangles,
         n[3] = mk4(u2f((uint32_t)link_of(bn[i].child[0])), u2f((uint32_t)link_of(bn[i].child[1])), 0.0f, 0.0f);
     }
     out.root = link_of(root);
+
+    // 4-wide tree for the persistent kernel: each wide node takes the children of a
+    // binary node and keeps replacing the child of largest surface area by its own
+    // two children until there are four (or only leaves remain).  Node layout
+    // (8 x f4, 128 bytes): lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] links[4] pad;
+    // unused slots (only ever slots 2 and 3) carry the link kNoRoot, which the visit checks.
+    if (bn[root].child[0] < 0) {
+        out.root4 = out.root; // a single leaf
+        out.max_stack4 = 0;
+        return;
+    }
+    struct Wide { int32_t bin_node; int32_t child[4]; int n; };
+    std::vector<Wide> wide;
+    std::vector<int32_t> wide_of(bn.size(), -1);
+    // breadth-first so that the top of the tree is contiguous in memory
+    std::vector<int32_t> queue{root};
+    for (size_t qi = 0; qi < queue.size(); qi++) {
+        int32_t bi = queue[qi];
+        Wide w;
+        w.bin_node = bi;
+        w.n = 2;
+        w.child[0] = bn[bi].child[0];
+        w.child[1] = bn[bi].child[1];
+        while (w.n < 4) {
+            int best = -1;
+            float best_area = -1.0f;
+            for (int k = 0; k < w.n; k++) {
+                if (bn[w.child[k]].child[0] < 0) continue;
+                float a = bn[w.child[k]].box.half_area();
+                if (a > best_area) { best_area = a; best = k; }
+            }
+            if (best < 0) break;
+            int32_t c = w.child[best];
+            w.child[best] = bn[c].child[0];
+            w.child[w.n++] = bn[c].child[1];
+        }
+        wide_of[bi] = (int32_t)wide.size();
+        wide.push_back(w);
+        for (int k = 0; k < w.n; k++)
+            if (bn[w.child[k]].child[0] >= 0) queue.push_back(w.child[k]);
+    }
+    out.nodes4.assign(wide.size() * 8, mk4(0, 0, 0, 0));
+    for (size_t wi = 0; wi < wide.size(); wi++) {
+        const Wide &w = wide[wi];
+        float v[6][4];
+        uint32_t link[4];
+        for (int k = 0; k < 4; k++) {
+            if (k < w.n) {
+                const Box &cb = bn[w.child[k]].box;
+                for (int a = 0; a < 3; a++) { v[a][k] = cb.lo[a]; v[3 + a][k] = cb.hi[a]; }
+                int32_t c = w.child[k];
+                link[k] = (uint32_t)(bn[c].child[0] >= 0 ? wide_of[c] : leaf_link(bn[c].first, bn[c].count));
+            } else {
+                for (int a = 0; a < 3; a++) { v[a][k] = 0.0f; v[3 + a][k] = 0.0f; }
+                link[k] = (uint32_t)kNoRoot;
+            }
+        }
+        f4 *n = &out.nodes4[8 * wi];
+        for (int r = 0; r < 6; r++) n[r] = mk4(v[r][0], v[r][1], v[r][2], v[r][3]);
+        n[6] = mk4(u2f(link[0]), u2f(link[1]), u2f(link[2]), u2f(link[3]));
+    }
+    out.root4 = 0;
+    // Deepest the traversal stack can get: every visit may leave up to (children - 1) entries behind.
+    std::vector<uint32_t> need(wide.size(), 0);
+    for (size_t wi = wide.size(); wi-- > 0;) {
+        const Wide &w = wide[wi];
+        uint32_t below = 0;
+        for (int k = 0; k < w.n; k++)
+            if (bn[w.child[k]].child[0] >= 0) below = std::max(below, need[wide_of[w.child[k]]]);
+        need[wi] = (uint32_t)(w.n - 1) + below;
+    }
+    out.max_stack4 = need[0];
 }
 
 bool make_frame_params(const void *uniforms80, uint32_t max_bounces, FrameParams &fp, std::string &err)

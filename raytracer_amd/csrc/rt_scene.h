@@ -12,11 +12,12 @@
 namespace rt {
 
 struct BuiltScene {
-    std::vector<f4> nodes, tri_isect, tri_shade, tri_raw, spheres, lights;
+    std::vector<f4> nodes, nodes4, tri_isect, tri_shade, tri_raw, spheres, lights;
     uint32_t n_spheres = 0, n_tris = 0, n_lights = 0, n_lights_pass1 = 0;
     float total_power = 0.0f;
-    int32_t root = kNoRoot;
+    int32_t root = kNoRoot, root4 = kNoRoot;
     uint32_t n_leaves = 0, max_depth = 0;
+    uint32_t max_stack4 = 0; // entries the 4-wide traversal can have on its stack at once
 };
 
 struct BuildOptions {

@@ -39,7 +39,7 @@ extern "C" int har_render_frame(const void *uniforms80, const void *spheres, uin
     std::string err;
     if (!rt::make_frame_params(uniforms80, max_bounces, fp, err)) return -1;
     rt::SceneView sc;
-    sc.nodes = bs.nodes.data(); sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data();
+    sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data();
     sc.tri_raw = bs.tri_raw.data(); sc.spheres = bs.spheres.data(); sc.lights = bs.lights.data();
     sc.n_spheres = bs.n_spheres; sc.n_tris = bs.n_tris; sc.n_lights = bs.n_lights;
     sc.n_lights_pass1 = bs.n_lights_pass1; sc.total_power = bs.total_power; sc.root = bs.root;
@@ -99,7 +99,7 @@ extern "C" int har_debug_pixel(const void *uniforms80, const void *spheres, uint
     std::string err;
     if (!rt::make_frame_params(uniforms80, max_bounces, fp, err)) return -1;
     rt::SceneView sc;
-    sc.nodes = bs.nodes.data(); sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data();
+    sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data();
     sc.tri_raw = bs.tri_raw.data(); sc.spheres = bs.spheres.data(); sc.lights = bs.lights.data();
     sc.n_spheres = bs.n_spheres; sc.n_tris = bs.n_tris; sc.n_lights = bs.n_lights;
     sc.n_lights_pass1 = bs.n_lights_pass1; sc.total_power = bs.total_power; sc.root = bs.root;
@@ -171,7 +171,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
     std::string err;
     if (!rt::make_frame_params(uni, max_bounces, fp, err)) return -1;
     rt::SceneView sc;
-    sc.nodes = bs.nodes.data(); sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data();
+    sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data();
     sc.tri_raw = bs.tri_raw.data(); sc.spheres = bs.spheres.data(); sc.lights = bs.lights.data();
     sc.n_spheres = bs.n_spheres; sc.n_tris = bs.n_tris; sc.n_lights = bs.n_lights;
     sc.n_lights_pass1 = bs.n_lights_pass1; sc.total_power = bs.total_power; sc.root = bs.root;
@@ -226,7 +226,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
                 if (!n_trav) break;
                 if (n_shade && n_trav * 8 < (n_trav + n_shade) * shade_num) break;
                 for (int i = 0; i < 64; i++)
-                    if (L[i].mode == rt::kLaneTraverse && rt::link_is_inner(L[i].cur)) rt::lane_step_inner(sc, L[i], st[i], nullptr);
+                    if (L[i].mode == rt::kLaneTraverse && rt::link_is_inner(L[i].cur)) rt::lane_step_node(sc, L[i], st[i], nullptr);
                 int n_leaf = 0, n_inner = 0;
                 for (auto &l : L) {
                     n_leaf += l.mode == rt::kLaneTraverse && rt::link_is_leaf(l.cur);
@@ -269,6 +269,6 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
             if (k + 1 == n_frames && frame_f16) std::memcpy(frame_f16 + 4 * p, src, 8);
         }
     }
-    if (counters) { counters[0] += rays; counters[13] += traversed; }
+    if (counters) { counters[0] += rays; counters[13] += traversed; counters[14] = bs.max_stack4; counters[15] = bs.nodes4.size() / 8; }
     return 0;
 }
