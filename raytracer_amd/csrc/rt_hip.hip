@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 #include <new>
 #include <string>
 #include <vector>
@@ -46,17 +47,30 @@ __host__ __device__ inline int stripe_global_row(const StripeMap &m, int local)
 // Per-lane traversal stack in LDS: entry k of lane l lives at base[k * BLOCK + l],
 // so one wave's pushes/pops touch 64 consecutive dwords (no bank conflicts).
 // ---------------------------------------------------------------------------
-template <int BLOCK>
+#ifndef RT_LDS_PARK
+#define RT_LDS_PARK 1
+#endif
+
+template <int BLOCK, class Entry>
 struct LdsStack {
-    int32_t *base;
+    Entry *base;
     int sp;
     __device__ void reset() { sp = 0; }
-    __device__ void push(int32_t v) { base[sp * BLOCK] = v; sp++; }
-    __device__ int32_t pop() { sp--; return base[sp * BLOCK]; }
+    __device__ void push(int32_t v) { base[sp * BLOCK] = (Entry)v; sp++; }
+    __device__ int32_t pop() { sp--; return (int32_t)base[sp * BLOCK]; }
     __device__ bool empty() const { return sp == 0; }
-    __device__ int32_t peek() const { return base[(sp > 0 ? sp - 1 : 0) * BLOCK]; }
-    __device__ void poke(int32_t v) { base[sp * BLOCK] = v; }
+    __device__ int32_t peek() const { return (int32_t)base[(sp > 0 ? sp - 1 : 0) * BLOCK]; }
+    __device__ void poke(int32_t v) { base[sp * BLOCK] = (Entry)v; }
     __device__ void advance(int d) { sp += d; }
+};
+
+// The 12 floats a lane sets aside during a shadow ray (rt::RegPark's interface), in LDS:
+// slot k of lane l lives at base[k * BLOCK + l].
+template <int BLOCK>
+struct LdsPark {
+    float *base;
+    __device__ void put(int slot, float x) { base[slot * BLOCK] = x; }
+    __device__ float get(int slot) const { return base[slot * BLOCK]; }
 };
 
 __device__ inline uint32_t wave_sum(uint32_t v)
@@ -114,7 +128,7 @@ __global__ __launch_bounds__(kBlock) void render_tiles_kernel(rt::SceneView sc, 
     if (px < fp.width && ly < local_rows) {
         const int py = stripe_global_row(sm, ly);
         if (py < fp.height) {
-            LdsStack<kBlock> stack;
+            LdsStack<kBlock, int32_t> stack;
             stack.base = lds_stack + threadIdx.x;
             stack.sp = 0;
             int32_t pid;
@@ -169,16 +183,24 @@ struct BatchParams {
     uint2 *colors;        // [n_frames][local_rows * width] rgba16float bit patterns (unused when FUSED)
 };
 
-template <int STACK, bool COUNT, bool FUSED>
+// SMALL: links fit 16 bits (<= 4096 triangles), so the stack uses 16-bit entries and the room
+// saved in LDS holds the values parked during shadow rays; otherwise 32-bit entries and
+// registers.
+template <int STACK, bool COUNT, bool FUSED, bool SMALL>
 __global__ __launch_bounds__(kBlock, RT_MINW) void render_persistent_kernel(rt::SceneView sc, rt::FrameParams fp, StripeMap sm,
                                                                     int local_rows, FrameBuffers fb, BatchParams bp,
                                                                     unsigned int *work_counter, SchedParams sched)
 {
-    __shared__ int32_t lds_stack[STACK * kBlock];
+    using StackEntry = typename std::conditional<SMALL, int16_t, int32_t>::type;
+    using ParkT = typename std::conditional<SMALL, LdsPark<kBlock>, rt::RegPark>::type;
+    __shared__ StackEntry lds_stack[STACK * kBlock];
+    __shared__ float lds_park[SMALL ? rt::kParkFloats * kBlock : 1];
     const int lane = threadIdx.x & 63;
-    LdsStack<kBlock> stack;
+    LdsStack<kBlock, StackEntry> stack;
     stack.base = lds_stack + threadIdx.x;
     stack.sp = 0;
+    ParkT park;
+    if constexpr (SMALL) park.base = lds_park + threadIdx.x;
 
     const uint32_t tiles_x = (uint32_t)(fp.width + 7) / 8u, tiles_y = (uint32_t)(local_rows + 7) / 8u;
     const uint32_t tiles_per_frame = tiles_x * tiles_y;
@@ -200,16 +222,19 @@ __global__ __launch_bounds__(kBlock, RT_MINW) void render_persistent_kernel(rt::
         // ---- store finished pixels -----------------------------------------------------------
         if (L.mode == rt::kLanePixelDone) {
             rt::f3 color = rt::lane_pixel_color(fp, L);
-            if (FUSED) store_pixel(fp, fb, L.px, L.py, color, L.primary_id);
+            uint32_t tile_all = L.unit >> 6, slot = L.unit & 63u;
+            uint32_t frame_k = tile_all / tiles_per_frame, tile = tile_all % tiles_per_frame;
+            int px = (int)((tile % tiles_x) * 8u + (slot & 7u));
+            int ly = (int)((tile / tiles_x) * 8u + (slot >> 3));
+            int py = stripe_global_row(sm, ly);
+            if (FUSED) store_pixel(fp, fb, px, py, color, rt::lane_primary_id(L));
             else {
-                // local row of py: inverse of stripe_global_row
-                int ly = (L.py / (sm.rows * sm.count)) * sm.rows + L.py % sm.rows;
-                size_t lp = (size_t)ly * fp.width + L.px;
+                size_t lp = (size_t)ly * fp.width + px;
                 uint2 packed;
                 packed.x = (uint32_t)rt::f32_to_f16_bits(color.x) | ((uint32_t)rt::f32_to_f16_bits(color.y) << 16);
                 packed.y = (uint32_t)rt::f32_to_f16_bits(color.z) | (0x3c00u << 16);
-                bp.colors[(size_t)L.frame_k * ((size_t)local_rows * fp.width) + lp] = packed;
-                if (L.frame_k + 1u == bp.n_frames) fb.ids[(size_t)L.py * fp.width + L.px] = L.primary_id;
+                bp.colors[(size_t)frame_k * ((size_t)local_rows * fp.width) + lp] = packed;
+                if (frame_k + 1u == bp.n_frames) fb.ids[(size_t)py * fp.width + px] = rt::lane_primary_id(L);
             }
             L.mode = rt::kLaneNeedUnit;
         }
@@ -245,18 +270,16 @@ __global__ __launch_bounds__(kBlock, RT_MINW) void render_persistent_kernel(rt::
                     int ly = (int)((tile / tiles_x) * 8u + (slot >> 3));
                     int py = stripe_global_row(sm, ly);
                     if (px < fp.width && ly < local_rows && py < fp.height) {
-                        L.px = px;
-                        L.py = py;
-                        L.frame_k = frame_k;
+                        L.unit = unit;
                         if (fp.max_bounces == 0u) {
                             // the bounce loop never runs: zero radiance, no rays (raytracer_compute.wgsl:196)
                             L.total = rt::mk3(0.0f, 0.0f, 0.0f);
-                            L.primary_id = -1;
+                            L.prim_best_id = rt::kNoHit;
                             L.mode = rt::kLanePixelDone;
                         } else {
                             rt::FrameParams f = fp;
                             if (!FUSED) f.seed_add = (uint32_t)(float)(bp.first_frame + frame_k) * 12345u;
-                            rt::lane_begin_pixel(sc, f, L, stack, n_rays, cp);
+                            rt::lane_begin_pixel(sc, f, L, px, py, stack, n_rays, cp);
                         }
                     }
                 }
@@ -293,7 +316,7 @@ __global__ __launch_bounds__(kBlock, RT_MINW) void render_persistent_kernel(rt::
             n_sdone = __popcll(__ballot(sdone));
             if (n_sdone != 0 && (n_sdone >= sched.sdone_lanes || __ballot(L.mode == rt::kLaneTraverse) == 0ull)) {
                 if (COUNT) { ph_sdone_it++; ph_sdone_ln += n_sdone; tc0 = clock64(); }
-                if (sdone) rt::lane_shadow_done(sc, fp, L, stack, n_rays, cp);
+                if (sdone) rt::lane_shadow_done(sc, fp, L, stack, park, n_rays, cp);
                 if (COUNT) tc_sdone += clock64() - tc0;
             }
         }
@@ -301,7 +324,7 @@ __global__ __launch_bounds__(kBlock, RT_MINW) void render_persistent_kernel(rt::
         // ---- shade the lanes whose closest-hit ray is finished ------------------------------------
         if (COUNT) { int n_sh = __popcll(__ballot(L.mode == rt::kLaneShadeClosest)); if (n_sh) { ph_shade_it++; ph_shade_ln += n_sh; } }
         if (COUNT) tc0 = clock64();
-        if (L.mode == rt::kLaneShadeClosest) rt::lane_shade_closest(sc, fp, L, stack, n_rays, cp);
+        if (L.mode == rt::kLaneShadeClosest) rt::lane_shade_closest(sc, fp, L, stack, park, n_rays, cp);
         if (COUNT) tc_shade += clock64() - tc0;
     }
     if (COUNT) tc_total = clock64() - tc_begin;
@@ -483,10 +506,10 @@ int launch_tiles(rt_context *c, const rt::FrameParams &fp)
     return RT_OK;
 }
 
-template <int STACK, bool COUNT, bool FUSED>
+template <int STACK, bool COUNT, bool FUSED, bool SMALL>
 int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchParams &bp, unsigned int *counter)
 {
-    auto kernel = render_persistent_kernel<STACK, COUNT, FUSED>;
+    auto kernel = render_persistent_kernel<STACK, COUNT, FUSED, SMALL>;
     int per_cu = c->tune_blocks_per_cu;
     if (per_cu <= 0) {
         RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
@@ -507,9 +530,16 @@ int launch_persistent_d(rt_context *c, const rt::FrameParams &fp, const BatchPar
 {
     // entries the traversal stack must hold (one spare for the binary tree's branch-free variant)
     uint32_t depth = rt::kWideBvh ? c->host_scene.max_stack4 : c->host_scene.max_depth + 1;
-    if (depth <= 16) return launch_persistent_t<16, COUNT, FUSED>(c, fp, bp, counter);
-    if (depth <= 32) return launch_persistent_t<32, COUNT, FUSED>(c, fp, bp, counter);
-    if (depth <= 64) return launch_persistent_t<64, COUNT, FUSED>(c, fp, bp, counter);
+    // 16-bit links: node indices below 32768 and leaf codes (first << 3 | count - 1) below 32768
+    const rt::BuiltScene &hs = c->host_scene;
+    bool small = RT_LDS_PARK && hs.n_tris <= 4096 && hs.nodes.size() / 4 < 32768 && hs.nodes4.size() / 8 < 32768 && depth <= 32;
+    if (small) {
+        if (depth <= 16) return launch_persistent_t<16, COUNT, FUSED, true>(c, fp, bp, counter);
+        return launch_persistent_t<32, COUNT, FUSED, true>(c, fp, bp, counter);
+    }
+    if (depth <= 16) return launch_persistent_t<16, COUNT, FUSED, false>(c, fp, bp, counter);
+    if (depth <= 32) return launch_persistent_t<32, COUNT, FUSED, false>(c, fp, bp, counter);
+    if (depth <= 64) return launch_persistent_t<64, COUNT, FUSED, false>(c, fp, bp, counter);
     return fail(RT_ERR_UNSUPPORTED, "acceleration structure too deep for the traversal stack");
 }
 
@@ -688,6 +718,7 @@ int rt_set_uniforms(rt_context *c, const void *uniforms80)
 int rt_set_max_bounces(rt_context *c, uint32_t max_bounces)
 {
     if (!c) return fail(RT_ERR_INVALID, "null context");
+    if (max_bounces > 255u) return fail(RT_ERR_INVALID, "max_bounces must be at most 255");
     c->max_bounces = max_bounces;
     return RT_OK;
 }

@@ -29,6 +29,9 @@
 #ifndef RT_WIDE_BVH
 #define RT_WIDE_BVH 1 // the lane state machine traverses the 4-wide tree (0: the binary tree)
 #endif
+#ifndef RT_SPHERE_BOX
+#define RT_SPHERE_BOX 0 // 1: reject spheres by a padded bounding-box test first (measured 11% slower: register pressure)
+#endif
 #ifndef RT_FLAT_INNER
 #define RT_FLAT_INNER 0
 #endif
@@ -56,31 +59,64 @@ struct RayCounts {
     uint32_t calls, traversed;
 };
 
+// Per-lane state.  Fields that are touched once per ray or less are packed so that the
+// traversal loop, which only needs the ray, keeps them in few registers.
 struct Lane {
     int32_t mode;
     // pixel / frame
-    int32_t px, py;
-    uint32_t frame_k;
-    uint32_t rng, sample, bounce;
+    uint32_t unit;        // (frame, pixel) unit number handed out by the scheduler
+    uint32_t rng;
+    uint32_t bits;        // sample (bits 0-15), bounce (16-23), flags (24-27), see below
     f3 prim_d, total;
-    int32_t primary_id;
     float prim_t;         // closest hit of the camera ray, traced once per pixel-frame:
     int32_t prim_best_id; // every sample of a frame starts on the same ray (raytracer_compute.wgsl:329-336)
     // path
     f3 color, light;
-    bool spec;
     // ray in flight
     f3 o, d;
     RayBox rb;
     float tmax;      // closest: best t so far; shadow: the limit distance - 0.1
     int32_t best_id; // closest: best id so far; shadow: kNoHit until an occluder is found
     int32_t cur;     // node link being visited; kNoRoot when the traversal is over
-    bool anyhit;
-    // parked while the shadow ray is in flight
-    f3 next_o, next_d; // next bounce ray
-    f3 nee, em;        // pending additions to light
-    bool has_em, path_continues;
 };
+
+// What a lane sets aside while its shadow ray is in flight: the next bounce ray and the two
+// pending additions to `light`.  Written by lane_shade_closest, read back by lane_shadow_done.
+// `Park` policies provide put(slot, value) / get(slot) for 12 floats; this one keeps them in
+// registers, the kernel's LDS policy keeps them in shared memory.
+enum { kParkNextO = 0, kParkNextD = 3, kParkNee = 6, kParkEm = 9, kParkFloats = 12 };
+
+struct RegPark {
+    float v[kParkFloats];
+    RT_HD void put(int slot, float x) { v[slot] = x; }
+    RT_HD float get(int slot) const { return v[slot]; }
+};
+
+template <class Park>
+RT_HD void park_put3(Park &park, int slot, f3 a)
+{
+    park.put(slot, a.x);
+    park.put(slot + 1, a.y);
+    park.put(slot + 2, a.z);
+}
+
+template <class Park>
+RT_HD f3 park_get3(const Park &park, int slot)
+{
+    return mk3(park.get(slot), park.get(slot + 1), park.get(slot + 2));
+}
+
+constexpr uint32_t kBitSpec = 1u << 24;     // is_specular_bounce of the path
+constexpr uint32_t kBitAnyhit = 1u << 25;   // the ray in flight is a shadow ray
+constexpr uint32_t kBitHasEm = 1u << 26;    // L.em is to be added to light
+constexpr uint32_t kBitContinue = 1u << 27; // the path goes on after the shadow ray
+
+RT_HD uint32_t lane_sample(const Lane &L) { return L.bits & 0xffffu; }
+RT_HD uint32_t lane_bounce(const Lane &L) { return (L.bits >> 16) & 0xffu; }
+RT_HD bool lane_flag(const Lane &L, uint32_t bit) { return (L.bits & bit) != 0u; }
+RT_HD void lane_set_flag(Lane &L, uint32_t bit, bool on) { L.bits = on ? (L.bits | bit) : (L.bits & ~bit); }
+// primary-hit id of the pixel (-1 on a miss), valid once the camera ray has been shaded
+RT_HD int32_t lane_primary_id(const Lane &L) { return L.prim_best_id == kNoHit ? -1 : L.prim_best_id; }
 
 RT_HD bool link_is_inner(int32_t cur) { return cur >= 0 && cur != kNoRoot; }
 RT_HD bool link_is_leaf(int32_t cur) { return cur < 0; }
@@ -88,7 +124,7 @@ RT_HD bool link_is_leaf(int32_t cur) { return cur < 0; }
 template <class Stack>
 RT_HD void lane_pop(Lane &L, Stack &stack)
 {
-    if (stack.empty()) { L.cur = kNoRoot; L.mode = L.anyhit ? kLaneShadowDone : kLaneShadeClosest; }
+    if (stack.empty()) { L.cur = kNoRoot; L.mode = lane_flag(L, kBitAnyhit) ? kLaneShadowDone : kLaneShadeClosest; }
     else L.cur = stack.pop();
 }
 
@@ -97,11 +133,16 @@ RT_HD void lane_pop(Lane &L, Stack &stack)
 RT_HD void lane_test_spheres(const SceneView &sc, Lane &L, TestCounts *cnt)
 {
     for (uint32_t i = 0; i < sc.n_spheres; i++) {
+        f4 s0 = sc.spheres[4 * i];
+        // Conservative rejection: a ray that misses the sphere's bounding box, widened by far
+        // more than f32 rounding can move the discriminant, gets -1 from sphere_t anyway.
+        float pad = fabsf(s0.w) * 1.001f + 1e-3f, tn_box;
+        if (RT_SPHERE_BOX && !slab(L.rb, s0.x - pad, s0.y - pad, s0.z - pad, s0.x + pad, s0.y + pad, s0.z + pad, INFINITY, tn_box)) continue;
         float tn;
-        float t = sphere_t(L.o, L.d, sc.spheres[4 * i], tn);
+        float t = sphere_t(L.o, L.d, s0, tn);
         if (cnt) cnt->spheres++;
         if (!(t > 0.0f)) continue;
-        if (L.anyhit) {
+        if (lane_flag(L, kBitAnyhit)) {
             if (!(t > L.tmax)) { L.best_id = (int32_t)i; L.cur = kNoRoot; }
         } else if (t < L.tmax || (t == L.tmax && (int32_t)i < L.best_id)) {
             L.tmax = t;
@@ -117,7 +158,7 @@ RT_HD void lane_launch_ray(const SceneView &sc, Lane &L, Stack &stack, bool anyh
 {
     n_rays.calls++;
     n_rays.traversed++;
-    L.anyhit = anyhit;
+    lane_set_flag(L, kBitAnyhit, anyhit);
     L.tmax = anyhit ? limit : INFINITY;
     L.best_id = kNoHit;
     L.mode = kLaneTraverse;
@@ -125,8 +166,8 @@ RT_HD void lane_launch_ray(const SceneView &sc, Lane &L, Stack &stack, bool anyh
     L.cur = kWideBvh ? sc.root4 : sc.root;
     if (all_nan(L.d)) L.cur = kNoRoot; // every test of the reference fails on a NaN direction
     else {
-        lane_test_spheres(sc, L, cnt);
         L.rb = make_raybox(L.o, L.d);
+        lane_test_spheres(sc, L, cnt);
     }
     if (L.cur == kNoRoot) L.mode = anyhit ? kLaneShadowDone : kLaneShadeClosest;
 }
@@ -174,7 +215,7 @@ RT_HD void lane_step_inner(const SceneView &sc, Lane &L, Stack &stack, TestCount
     bool empty = stack.empty();
     stack.advance(both ? 1 : ((none & !empty) ? -1 : 0));
     L.cur = none ? (empty ? kNoRoot : top) : near;
-    if (none & empty) L.mode = L.anyhit ? kLaneShadowDone : kLaneShadeClosest;
+    if (none & empty) L.mode = lane_flag(L, kBitAnyhit) ? kLaneShadowDone : kLaneShadeClosest;
 }
 
 #endif
@@ -237,12 +278,13 @@ RT_HD void lane_step_triangle(const SceneView &sc, Lane &L, Stack &stack, TestCo
     if (t > 0.0f) {
         uint32_t orig = f2u(c.y);
         int32_t id = (int32_t)(orig + sc.n_spheres);
-        bool candidate = L.anyhit ? !(t > L.tmax) : (t < L.tmax || (t == L.tmax && id < L.best_id));
+        bool anyhit = lane_flag(L, kBitAnyhit);
+        bool candidate = anyhit ? !(t > L.tmax) : (t < L.tmax || (t == L.tmax && id < L.best_id));
         if (candidate) {
             f3 nrm = xyz(kTriRecord == 4 ? tr[3] : sc.tri_shade[3 * (size_t)orig]); // common.wgsl:202-207
             if (!(dot(nrm, L.d) > 0.0f)) {
                 L.best_id = id;
-                if (L.anyhit) stop = true;
+                if (anyhit) stop = true;
                 else L.tmax = t;
             }
         }
@@ -259,15 +301,13 @@ RT_HD void lane_step_triangle(const SceneView &sc, Lane &L, Stack &stack, TestCo
 RT_HD void lane_end_path(const FrameParams &fp, Lane &L, RayCounts &n_rays)
 {
     L.total = add(L.total, L.light);
-    L.sample++;
-    if (L.sample < fp.spp) {
+    uint32_t sample = lane_sample(L) + 1u;
+    if (sample < fp.spp) {
+        L.bits = sample; // bounce 0, no flags: not specular, closest-hit result
         L.color = mk3(1.0f, 1.0f, 1.0f);
         L.light = mk3(0.0f, 0.0f, 0.0f);
-        L.spec = false;
-        L.bounce = 0;
         L.o = fp.cam_pos;
         L.d = L.prim_d;
-        L.anyhit = false;
         L.tmax = L.prim_t;
         L.best_id = L.prim_best_id;
         L.cur = kNoRoot;
@@ -280,17 +320,15 @@ RT_HD void lane_end_path(const FrameParams &fp, Lane &L, RayCounts &n_rays)
 
 // Seed, jitter, camera ray and the first path of a pixel (raytracer_compute.wgsl:293-336).
 template <class Stack>
-RT_HD void lane_begin_pixel(const SceneView &sc, const FrameParams &fp, Lane &L, Stack &stack, RayCounts &n_rays,
-                            TestCounts *cnt)
+RT_HD void lane_begin_pixel(const SceneView &sc, const FrameParams &fp, Lane &L, int px, int py, Stack &stack,
+                            RayCounts &n_rays, TestCounts *cnt)
 {
-    L.prim_d = primary_direction(fp, L.px, L.py, L.rng);
+    L.prim_d = primary_direction(fp, px, py, L.rng);
     L.total = mk3(0.0f, 0.0f, 0.0f);
-    L.sample = 0;
-    L.primary_id = -1;
+    L.bits = 0u;
+    L.prim_best_id = kNoHit;
     L.color = mk3(1.0f, 1.0f, 1.0f);
     L.light = mk3(0.0f, 0.0f, 0.0f);
-    L.spec = false;
-    L.bounce = 0;
     L.o = fp.cam_pos;
     L.d = L.prim_d;
     lane_launch_ray(sc, L, stack, false, 0.0f, n_rays, cnt);
@@ -300,14 +338,14 @@ RT_HD void lane_begin_pixel(const SceneView &sc, const FrameParams &fp, Lane &L,
 RT_HD f3 lane_pixel_color(const FrameParams &fp, const Lane &L) { return divs(L.total, fp.spp_f); }
 
 // Lane in kLaneShadeClosest: consumes the closest-hit result.
-template <class Stack>
-RT_HD void lane_shade_closest(const SceneView &sc, const FrameParams &fp, Lane &L, Stack &stack, RayCounts &n_rays,
-                              TestCounts *cnt)
+template <class Stack, class Park>
+RT_HD void lane_shade_closest(const SceneView &sc, const FrameParams &fp, Lane &L, Stack &stack, Park &park,
+                              RayCounts &n_rays, TestCounts *cnt)
 {
     int32_t id = (L.best_id == kNoHit) ? -1 : L.best_id;
     float t = L.tmax;
-    if (L.bounce == 0u && L.sample == 0u) {
-        L.primary_id = id;
+    uint32_t bounce = lane_bounce(L);
+    if ((L.bits & 0xffffffu) == 0u) { // first bounce of the first sample: remember the camera ray's hit
         L.prim_t = L.tmax;
         L.prim_best_id = L.best_id;
     }
@@ -325,25 +363,28 @@ RT_HD void lane_shade_closest(const SceneView &sc, const FrameParams &fp, Lane &
         if (ts.pdf > 0.0f) {
             float cos_theta = dot(hit.normal, ts.direction);
             if (cos_theta > 0.0f) {
-                L.nee = nee_contribution(ts, hit.normal, cos_theta, L.color);
+                park_put3(park, kParkNee, nee_contribution(ts, hit.normal, cos_theta, L.color));
                 shadow = true;
             }
         }
-        f3 no = L.o, nd = L.d;
-        bool alive = finish_bounce(hit, L.bounce, no, nd, L.color, L.em, L.has_em, L.spec, L.rng);
-        L.bounce++;
-        bool cont = alive && L.bounce < fp.max_bounces;
+        f3 no = L.o, nd = L.d, em;
+        bool has_em, spec = lane_flag(L, kBitSpec);
+        bool alive = finish_bounce(hit, bounce, no, nd, L.color, em, has_em, spec, L.rng);
+        bounce++;
+        bool cont = alive && bounce < fp.max_bounces;
+        L.bits = (L.bits & 0xffffu) | (bounce << 16) | (spec ? kBitSpec : 0u) | (has_em ? kBitHasEm : 0u) |
+                 (cont ? kBitContinue : 0u);
         if (shadow) {
-            L.next_o = no;
-            L.next_d = nd;
-            L.path_continues = cont;
+            park_put3(park, kParkNextO, no);
+            park_put3(park, kParkNextD, nd);
+            park_put3(park, kParkEm, em);
             L.o = add(hit_point, scale(hit.normal, 0.01f));
             L.d = ts.direction;
             launch = true;
             launch_anyhit = true;
             launch_limit = ts.distance - 0.1f;
         } else {
-            if (L.has_em) L.light = add(L.light, L.em);
+            if (has_em) L.light = add(L.light, em);
             if (cont) { L.o = no; L.d = nd; launch = true; }
             else end_path = true;
         }
@@ -353,15 +394,15 @@ RT_HD void lane_shade_closest(const SceneView &sc, const FrameParams &fp, Lane &
 }
 
 // Lane in kLaneShadowDone: consumes the shadow result (raytracer_compute.wgsl:219-224, :242).
-template <class Stack>
-RT_HD void lane_shadow_done(const SceneView &sc, const FrameParams &fp, Lane &L, Stack &stack, RayCounts &n_rays,
-                            TestCounts *cnt)
+template <class Stack, class Park>
+RT_HD void lane_shadow_done(const SceneView &sc, const FrameParams &fp, Lane &L, Stack &stack, const Park &park,
+                            RayCounts &n_rays, TestCounts *cnt)
 {
-    if (L.best_id == kNoHit) L.light = add(L.light, L.nee);
-    if (L.has_em) L.light = add(L.light, L.em);
-    if (L.path_continues) {
-        L.o = L.next_o;
-        L.d = L.next_d;
+    if (L.best_id == kNoHit) L.light = add(L.light, park_get3(park, kParkNee));
+    if (lane_flag(L, kBitHasEm)) L.light = add(L.light, park_get3(park, kParkEm));
+    if (lane_flag(L, kBitContinue)) {
+        L.o = park_get3(park, kParkNextO);
+        L.d = park_get3(park, kParkNextD);
         lane_launch_ray(sc, L, stack, false, 0.0f, n_rays, cnt);
     } else {
         lane_end_path(fp, L, n_rays);

@@ -186,6 +186,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
     auto wave = [&]() {
         rt::Lane L[64];
         HostStack st[64];
+        rt::RegPark park[64];
         for (auto &l : L) l.mode = rt::kLaneNeedUnit;
         rt::RayCounts n_rays = {0, 0};
         uint32_t pool_tile = 0, pool_next = 64;
@@ -209,10 +210,10 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
                     uint32_t frame_k = pool_tile / tiles_per_frame, tile = pool_tile % tiles_per_frame;
                     int px = (tile % tiles_x) * 8 + (slot & 7), py = (tile / tiles_x) * 8 + (slot >> 3);
                     if (px < W && py < H) {
-                        L[i].px = px; L[i].py = py; L[i].frame_k = frame_k;
+                        L[i].unit = (frame_k * H + py) * W + px; // this emulation numbers units row-major
                         rt::FrameParams f = fp;
                         f.seed_add = (uint32_t)(float)(first_frame + frame_k) * 12345u;
-                        rt::lane_begin_pixel(sc, f, L[i], st[i], n_rays, nullptr);
+                        rt::lane_begin_pixel(sc, f, L[i], px, py, st[i], n_rays, nullptr);
                     }
                 }
                 pool_next += std::min<uint32_t>(n_need, 64 - pool_next);
@@ -236,20 +237,21 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
                     for (int i = 0; i < 64; i++)
                         if (L[i].mode == rt::kLaneTraverse && rt::link_is_leaf(L[i].cur)) rt::lane_step_triangle(sc, L[i], st[i], nullptr);
                 for (int i = 0; i < 64; i++)
-                    if (L[i].mode == rt::kLaneShadowDone) rt::lane_shadow_done(sc, fp, L[i], st[i], n_rays, nullptr);
+                    if (L[i].mode == rt::kLaneShadowDone) rt::lane_shadow_done(sc, fp, L[i], st[i], park[i], n_rays, nullptr);
             }
             for (int i = 0; i < 64; i++) {
-                if (L[i].mode == rt::kLaneShadowDone) rt::lane_shadow_done(sc, fp, L[i], st[i], n_rays, nullptr);
-                if (L[i].mode == rt::kLaneShadeClosest) rt::lane_shade_closest(sc, fp, L[i], st[i], n_rays, nullptr);
+                if (L[i].mode == rt::kLaneShadowDone) rt::lane_shadow_done(sc, fp, L[i], st[i], park[i], n_rays, nullptr);
+                if (L[i].mode == rt::kLaneShadeClosest) rt::lane_shade_closest(sc, fp, L[i], st[i], park[i], n_rays, nullptr);
             }
             for (int i = 0; i < 64; i++) {
                 if (L[i].mode != rt::kLanePixelDone) continue;
                 rt::f3 c = rt::lane_pixel_color(fp, L[i]);
-                size_t p = (size_t)L[i].py * W + L[i].px;
-                uint16_t *dst = &batch[((size_t)L[i].frame_k * W * H + p) * 4];
+                size_t p = L[i].unit % ((size_t)W * H);
+                uint32_t frame_k = L[i].unit / ((uint32_t)W * H);
+                uint16_t *dst = &batch[((size_t)frame_k * W * H + p) * 4];
                 dst[0] = rt::f32_to_f16_bits(c.x); dst[1] = rt::f32_to_f16_bits(c.y);
                 dst[2] = rt::f32_to_f16_bits(c.z); dst[3] = 0x3c00;
-                if (L[i].frame_k + 1 == n_frames && ids) ids[p] = L[i].primary_id;
+                if (frame_k + 1 == n_frames && ids) ids[p] = rt::lane_primary_id(L[i]);
                 L[i].mode = rt::kLaneNeedUnit;
             }
         }
