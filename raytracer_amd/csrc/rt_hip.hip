@@ -48,7 +48,13 @@ __host__ __device__ inline int stripe_global_row(const StripeMap &m, int local)
 // so one wave's pushes/pops touch 64 consecutive dwords (no bank conflicts).
 // ---------------------------------------------------------------------------
 #ifndef RT_LDS_PARK
-#define RT_LDS_PARK 1
+#define RT_LDS_PARK 2
+#endif
+#ifndef RT_PARK2_STACK
+#define RT_PARK2_STACK 24
+#endif
+#ifndef RT_PARK2_SLOTS
+#define RT_PARK2_SLOTS 17
 #endif
 
 template <int BLOCK, class Entry>
@@ -64,13 +70,19 @@ struct LdsStack {
     __device__ void advance(int d) { sp += d; }
 };
 
-// The 12 floats a lane sets aside during a shadow ray (rt::RegPark's interface), in LDS:
-// slot k of lane l lives at base[k * BLOCK + l].
-template <int BLOCK>
+// rt::RegPark's interface with the first NLDS slots in LDS (slot k of lane l at
+// base[k * BLOCK + l]) and the rest in registers.  Slot numbers are compile-time constants at
+// every use, so each access resolves to one or the other.
+template <int BLOCK, int NLDS>
 struct LdsPark {
     float *base;
-    __device__ void put(int slot, float x) { base[slot * BLOCK] = x; }
-    __device__ float get(int slot) const { return base[slot * BLOCK]; }
+    float regs[NLDS < rt::kParkFloats ? rt::kParkFloats - NLDS : 1];
+    __device__ void put(int slot, float x)
+    {
+        if (slot < NLDS) base[slot * BLOCK] = x;
+        else regs[slot - NLDS] = x;
+    }
+    __device__ float get(int slot) const { return slot < NLDS ? base[slot * BLOCK] : regs[slot - NLDS]; }
 };
 
 __device__ inline uint32_t wave_sum(uint32_t v)
@@ -183,24 +195,25 @@ struct BatchParams {
     uint2 *colors;        // [n_frames][local_rows * width] rgba16float bit patterns (unused when FUSED)
 };
 
-// SMALL: links fit 16 bits (<= 4096 triangles), so the stack uses 16-bit entries and the room
-// saved in LDS holds the values parked during shadow rays; otherwise 32-bit entries and
-// registers.
-template <int STACK, bool COUNT, bool FUSED, bool SMALL>
+// PARK > 0: links fit 16 bits (<= 4096 triangles), so the stack uses 16-bit entries and the
+// room saved in LDS holds the first PARK slots of the lanes' rarely touched state (12: what is
+// set aside during shadow rays; 17: the per-pixel radiance sum and primary hit too).  PARK == 0:
+// 32-bit entries, all state in registers.  STACK * sizeof(entry) + PARK * 4 must stay below
+// 128 bytes per lane: at exactly 32 KB per block only four blocks fit a CU.
+template <int STACK, bool COUNT, bool FUSED, int PARK>
 __global__ __launch_bounds__(kBlock, RT_MINW) void render_persistent_kernel(rt::SceneView sc, rt::FrameParams fp, StripeMap sm,
                                                                     int local_rows, FrameBuffers fb, BatchParams bp,
                                                                     unsigned int *work_counter, SchedParams sched)
 {
-    using StackEntry = typename std::conditional<SMALL, int16_t, int32_t>::type;
-    using ParkT = typename std::conditional<SMALL, LdsPark<kBlock>, rt::RegPark>::type;
+    using StackEntry = typename std::conditional<(PARK > 0), int16_t, int32_t>::type;
     __shared__ StackEntry lds_stack[STACK * kBlock];
-    __shared__ float lds_park[SMALL ? rt::kParkFloats * kBlock : 1];
+    __shared__ float lds_park[PARK > 0 ? PARK * kBlock : 1];
     const int lane = threadIdx.x & 63;
     LdsStack<kBlock, StackEntry> stack;
     stack.base = lds_stack + threadIdx.x;
     stack.sp = 0;
-    ParkT park;
-    if constexpr (SMALL) park.base = lds_park + threadIdx.x;
+    LdsPark<kBlock, PARK> park;
+    park.base = lds_park + threadIdx.x;
 
     const uint32_t tiles_x = (uint32_t)(fp.width + 7) / 8u, tiles_y = (uint32_t)(local_rows + 7) / 8u;
     const uint32_t tiles_per_frame = tiles_x * tiles_y;
@@ -221,20 +234,20 @@ __global__ __launch_bounds__(kBlock, RT_MINW) void render_persistent_kernel(rt::
     for (;;) {
         // ---- store finished pixels -----------------------------------------------------------
         if (L.mode == rt::kLanePixelDone) {
-            rt::f3 color = rt::lane_pixel_color(fp, L);
+            rt::f3 color = rt::lane_pixel_color(fp, park);
             uint32_t tile_all = L.unit >> 6, slot = L.unit & 63u;
             uint32_t frame_k = tile_all / tiles_per_frame, tile = tile_all % tiles_per_frame;
             int px = (int)((tile % tiles_x) * 8u + (slot & 7u));
             int ly = (int)((tile / tiles_x) * 8u + (slot >> 3));
             int py = stripe_global_row(sm, ly);
-            if (FUSED) store_pixel(fp, fb, px, py, color, rt::lane_primary_id(L));
+            if (FUSED) store_pixel(fp, fb, px, py, color, rt::lane_primary_id(park));
             else {
                 size_t lp = (size_t)ly * fp.width + px;
                 uint2 packed;
                 packed.x = (uint32_t)rt::f32_to_f16_bits(color.x) | ((uint32_t)rt::f32_to_f16_bits(color.y) << 16);
                 packed.y = (uint32_t)rt::f32_to_f16_bits(color.z) | (0x3c00u << 16);
                 bp.colors[(size_t)frame_k * ((size_t)local_rows * fp.width) + lp] = packed;
-                if (frame_k + 1u == bp.n_frames) fb.ids[(size_t)py * fp.width + px] = rt::lane_primary_id(L);
+                if (frame_k + 1u == bp.n_frames) fb.ids[(size_t)py * fp.width + px] = rt::lane_primary_id(park);
             }
             L.mode = rt::kLaneNeedUnit;
         }
@@ -272,14 +285,11 @@ __global__ __launch_bounds__(kBlock, RT_MINW) void render_persistent_kernel(rt::
                     if (px < fp.width && ly < local_rows && py < fp.height) {
                         L.unit = unit;
                         if (fp.max_bounces == 0u) {
-                            // the bounce loop never runs: zero radiance, no rays (raytracer_compute.wgsl:196)
-                            L.total = rt::mk3(0.0f, 0.0f, 0.0f);
-                            L.prim_best_id = rt::kNoHit;
-                            L.mode = rt::kLanePixelDone;
+                            rt::lane_empty_pixel(L, park);
                         } else {
                             rt::FrameParams f = fp;
                             if (!FUSED) f.seed_add = (uint32_t)(float)(bp.first_frame + frame_k) * 12345u;
-                            rt::lane_begin_pixel(sc, f, L, px, py, stack, n_rays, cp);
+                            rt::lane_begin_pixel(sc, f, L, px, py, stack, park, n_rays, cp);
                         }
                     }
                 }
@@ -506,10 +516,10 @@ int launch_tiles(rt_context *c, const rt::FrameParams &fp)
     return RT_OK;
 }
 
-template <int STACK, bool COUNT, bool FUSED, bool SMALL>
+template <int STACK, bool COUNT, bool FUSED, int PARK>
 int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchParams &bp, unsigned int *counter)
 {
-    auto kernel = render_persistent_kernel<STACK, COUNT, FUSED, SMALL>;
+    auto kernel = render_persistent_kernel<STACK, COUNT, FUSED, PARK>;
     int per_cu = c->tune_blocks_per_cu;
     if (per_cu <= 0) {
         RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
@@ -534,12 +544,12 @@ int launch_persistent_d(rt_context *c, const rt::FrameParams &fp, const BatchPar
     const rt::BuiltScene &hs = c->host_scene;
     bool small = RT_LDS_PARK && hs.n_tris <= 4096 && hs.nodes.size() / 4 < 32768 && hs.nodes4.size() / 8 < 32768 && depth <= 32;
     if (small) {
-        if (depth <= 16) return launch_persistent_t<16, COUNT, FUSED, true>(c, fp, bp, counter);
-        return launch_persistent_t<32, COUNT, FUSED, true>(c, fp, bp, counter);
+        if (depth <= RT_PARK2_STACK && RT_LDS_PARK >= 2) return launch_persistent_t<RT_PARK2_STACK, COUNT, FUSED, RT_PARK2_SLOTS>(c, fp, bp, counter);
+        return launch_persistent_t<32, COUNT, FUSED, 12>(c, fp, bp, counter);
     }
-    if (depth <= 16) return launch_persistent_t<16, COUNT, FUSED, false>(c, fp, bp, counter);
-    if (depth <= 32) return launch_persistent_t<32, COUNT, FUSED, false>(c, fp, bp, counter);
-    if (depth <= 64) return launch_persistent_t<64, COUNT, FUSED, false>(c, fp, bp, counter);
+    if (depth <= 16) return launch_persistent_t<16, COUNT, FUSED, 0>(c, fp, bp, counter);
+    if (depth <= 32) return launch_persistent_t<32, COUNT, FUSED, 0>(c, fp, bp, counter);
+    if (depth <= 64) return launch_persistent_t<64, COUNT, FUSED, 0>(c, fp, bp, counter);
     return fail(RT_ERR_UNSUPPORTED, "acceleration structure too deep for the traversal stack");
 }
 

@@ -67,9 +67,6 @@ struct Lane {
     uint32_t unit;        // (frame, pixel) unit number handed out by the scheduler
     uint32_t rng;
     uint32_t bits;        // sample (bits 0-15), bounce (16-23), flags (24-27), see below
-    f3 prim_d, total;
-    float prim_t;         // closest hit of the camera ray, traced once per pixel-frame:
-    int32_t prim_best_id; // every sample of a frame starts on the same ray (raytracer_compute.wgsl:329-336)
     // path
     f3 color, light;
     // ray in flight
@@ -80,11 +77,19 @@ struct Lane {
     int32_t cur;     // node link being visited; kNoRoot when the traversal is over
 };
 
-// What a lane sets aside while its shadow ray is in flight: the next bounce ray and the two
-// pending additions to `light`.  Written by lane_shade_closest, read back by lane_shadow_done.
-// `Park` policies provide put(slot, value) / get(slot) for 12 floats; this one keeps them in
-// registers, the kernel's LDS policy keeps them in shared memory.
-enum { kParkNextO = 0, kParkNextD = 3, kParkNee = 6, kParkEm = 9, kParkFloats = 12 };
+// State a lane touches rarely, kept behind a `Park` policy (put(slot, value) / get(slot) on
+// kParkFloats floats) so that the kernel can hold it in LDS instead of registers:
+//  - what is set aside while a shadow ray is in flight (slots 0-11): the next bounce ray and
+//    the two pending additions to `light`, written by lane_shade_closest, read back by
+//    lane_shadow_done;
+//  - what lives for a whole pixel-frame (slots 12-19): the camera ray direction, its
+//    closest hit (every sample of a frame starts on the same ray, raytracer_compute.wgsl:329-336,
+//    so it is traced once) and the sum of the samples' radiance.
+// RegPark keeps everything in registers.
+enum {
+    kParkNextO = 0, kParkNextD = 3, kParkNee = 6, kParkEm = 9, kParkShadowFloats = 12,
+    kParkTotal = 12, kParkPrimT = 15, kParkPrimId = 16, kParkPrimD = 17, kParkFloats = 20
+};
 
 struct RegPark {
     float v[kParkFloats];
@@ -116,7 +121,12 @@ RT_HD uint32_t lane_bounce(const Lane &L) { return (L.bits >> 16) & 0xffu; }
 RT_HD bool lane_flag(const Lane &L, uint32_t bit) { return (L.bits & bit) != 0u; }
 RT_HD void lane_set_flag(Lane &L, uint32_t bit, bool on) { L.bits = on ? (L.bits | bit) : (L.bits & ~bit); }
 // primary-hit id of the pixel (-1 on a miss), valid once the camera ray has been shaded
-RT_HD int32_t lane_primary_id(const Lane &L) { return L.prim_best_id == kNoHit ? -1 : L.prim_best_id; }
+template <class Park>
+RT_HD int32_t lane_primary_id(const Park &park)
+{
+    int32_t id = (int32_t)f2u(park.get(kParkPrimId));
+    return id == kNoHit ? -1 : id;
+}
 
 RT_HD bool link_is_inner(int32_t cur) { return cur >= 0 && cur != kNoRoot; }
 RT_HD bool link_is_leaf(int32_t cur) { return cur < 0; }
@@ -298,18 +308,19 @@ RT_HD void lane_step_triangle(const SceneView &sc, Lane &L, Stack &stack, TestCo
 // next sample starts on the same camera ray, whose ray_all result is already
 // known, so the lane goes straight back to kLaneShadeClosest; after the last
 // sample the pixel is finished.
-RT_HD void lane_end_path(const FrameParams &fp, Lane &L, RayCounts &n_rays)
+template <class Park>
+RT_HD void lane_end_path(const FrameParams &fp, Lane &L, Park &park, RayCounts &n_rays)
 {
-    L.total = add(L.total, L.light);
+    park_put3(park, kParkTotal, add(park_get3(park, kParkTotal), L.light));
     uint32_t sample = lane_sample(L) + 1u;
     if (sample < fp.spp) {
         L.bits = sample; // bounce 0, no flags: not specular, closest-hit result
         L.color = mk3(1.0f, 1.0f, 1.0f);
         L.light = mk3(0.0f, 0.0f, 0.0f);
         L.o = fp.cam_pos;
-        L.d = L.prim_d;
-        L.tmax = L.prim_t;
-        L.best_id = L.prim_best_id;
+        L.d = park_get3(park, kParkPrimD);
+        L.tmax = park.get(kParkPrimT);
+        L.best_id = (int32_t)f2u(park.get(kParkPrimId));
         L.cur = kNoRoot;
         L.mode = kLaneShadeClosest;
         n_rays.calls++;
@@ -319,23 +330,34 @@ RT_HD void lane_end_path(const FrameParams &fp, Lane &L, RayCounts &n_rays)
 }
 
 // Seed, jitter, camera ray and the first path of a pixel (raytracer_compute.wgsl:293-336).
-template <class Stack>
+template <class Stack, class Park>
 RT_HD void lane_begin_pixel(const SceneView &sc, const FrameParams &fp, Lane &L, int px, int py, Stack &stack,
-                            RayCounts &n_rays, TestCounts *cnt)
+                            Park &park, RayCounts &n_rays, TestCounts *cnt)
 {
-    L.prim_d = primary_direction(fp, px, py, L.rng);
-    L.total = mk3(0.0f, 0.0f, 0.0f);
+    L.d = primary_direction(fp, px, py, L.rng);
+    park_put3(park, kParkPrimD, L.d);
+    park_put3(park, kParkTotal, mk3(0.0f, 0.0f, 0.0f));
+    park.put(kParkPrimId, u2f((uint32_t)kNoHit));
     L.bits = 0u;
-    L.prim_best_id = kNoHit;
     L.color = mk3(1.0f, 1.0f, 1.0f);
     L.light = mk3(0.0f, 0.0f, 0.0f);
     L.o = fp.cam_pos;
-    L.d = L.prim_d;
     lane_launch_ray(sc, L, stack, false, 0.0f, n_rays, cnt);
 }
 
 // Frame colour of a lane in kLanePixelDone (raytracer_compute.wgsl:337).
-RT_HD f3 lane_pixel_color(const FrameParams &fp, const Lane &L) { return divs(L.total, fp.spp_f); }
+template <class Park>
+RT_HD f3 lane_pixel_color(const FrameParams &fp, const Park &park) { return divs(park_get3(park, kParkTotal), fp.spp_f); }
+
+// A pixel of a frame whose bounce loop never runs (max_bounces 0): zero radiance, no rays
+// (raytracer_compute.wgsl:196).
+template <class Park>
+RT_HD void lane_empty_pixel(Lane &L, Park &park)
+{
+    park_put3(park, kParkTotal, mk3(0.0f, 0.0f, 0.0f));
+    park.put(kParkPrimId, u2f((uint32_t)kNoHit));
+    L.mode = kLanePixelDone;
+}
 
 // Lane in kLaneShadeClosest: consumes the closest-hit result.
 template <class Stack, class Park>
@@ -346,8 +368,8 @@ RT_HD void lane_shade_closest(const SceneView &sc, const FrameParams &fp, Lane &
     float t = L.tmax;
     uint32_t bounce = lane_bounce(L);
     if ((L.bits & 0xffffffu) == 0u) { // first bounce of the first sample: remember the camera ray's hit
-        L.prim_t = L.tmax;
-        L.prim_best_id = L.best_id;
+        park.put(kParkPrimT, L.tmax);
+        park.put(kParkPrimId, u2f((uint32_t)L.best_id));
     }
     bool end_path = false, launch = false, launch_anyhit = false;
     float launch_limit = 0.0f;
@@ -390,12 +412,12 @@ RT_HD void lane_shade_closest(const SceneView &sc, const FrameParams &fp, Lane &
         }
     }
     if (launch) lane_launch_ray(sc, L, stack, launch_anyhit, launch_limit, n_rays, cnt);
-    if (end_path) lane_end_path(fp, L, n_rays);
+    if (end_path) lane_end_path(fp, L, park, n_rays);
 }
 
 // Lane in kLaneShadowDone: consumes the shadow result (raytracer_compute.wgsl:219-224, :242).
 template <class Stack, class Park>
-RT_HD void lane_shadow_done(const SceneView &sc, const FrameParams &fp, Lane &L, Stack &stack, const Park &park,
+RT_HD void lane_shadow_done(const SceneView &sc, const FrameParams &fp, Lane &L, Stack &stack, Park &park,
                             RayCounts &n_rays, TestCounts *cnt)
 {
     if (L.best_id == kNoHit) L.light = add(L.light, park_get3(park, kParkNee));
@@ -405,7 +427,7 @@ RT_HD void lane_shadow_done(const SceneView &sc, const FrameParams &fp, Lane &L,
         L.d = park_get3(park, kParkNextD);
         lane_launch_ray(sc, L, stack, false, 0.0f, n_rays, cnt);
     } else {
-        lane_end_path(fp, L, n_rays);
+        lane_end_path(fp, L, park, n_rays);
     }
 }
 

@@ -213,7 +213,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
                         L[i].unit = (frame_k * H + py) * W + px; // this emulation numbers units row-major
                         rt::FrameParams f = fp;
                         f.seed_add = (uint32_t)(float)(first_frame + frame_k) * 12345u;
-                        rt::lane_begin_pixel(sc, f, L[i], px, py, st[i], n_rays, nullptr);
+                        rt::lane_begin_pixel(sc, f, L[i], px, py, st[i], park[i], n_rays, nullptr);
                     }
                 }
                 pool_next += std::min<uint32_t>(n_need, 64 - pool_next);
@@ -245,13 +245,13 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
             }
             for (int i = 0; i < 64; i++) {
                 if (L[i].mode != rt::kLanePixelDone) continue;
-                rt::f3 c = rt::lane_pixel_color(fp, L[i]);
+                rt::f3 c = rt::lane_pixel_color(fp, park[i]);
                 size_t p = L[i].unit % ((size_t)W * H);
                 uint32_t frame_k = L[i].unit / ((uint32_t)W * H);
                 uint16_t *dst = &batch[((size_t)frame_k * W * H + p) * 4];
                 dst[0] = rt::f32_to_f16_bits(c.x); dst[1] = rt::f32_to_f16_bits(c.y);
                 dst[2] = rt::f32_to_f16_bits(c.z); dst[3] = 0x3c00;
-                if (frame_k + 1 == n_frames && ids) ids[p] = rt::lane_primary_id(L[i]);
+                if (frame_k + 1 == n_frames && ids) ids[p] = rt::lane_primary_id(park[i]);
                 L[i].mode = rt::kLaneNeedUnit;
             }
         }
