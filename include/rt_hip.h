@@ -55,7 +55,9 @@ typedef enum rt_tuning {
     RT_TUNE_SHADOW_DONE_LANES = 4, /* finish shadow rays once this many lanes of a wave wait for it (1..64)     */
     RT_TUNE_REFILL_LANES = 5,  /* fetch new pixels once this many lanes of a wave are idle (1..64)              */
     RT_TUNE_MAX_LEAF = 6,      /* triangles per BVH leaf, 1..8; takes effect at the next rt_set_scene           */
-    RT_TUNE_TRI_COST_X10 = 7   /* SAH cost of a triangle test relative to a node visit, in tenths; next rt_set_scene */
+    RT_TUNE_TRI_COST_X10 = 7,  /* SAH cost of a triangle test relative to a node visit, in tenths; next rt_set_scene */
+    RT_TUNE_LDS_STATE = 8      /* scenes of <= 4096 triangles: 2 = per-pixel and shadow-ray lane state in LDS (default),
+                                  1 = shadow-ray state only, 0 = all lane state in registers (as for larger scenes)  */
 } rt_tuning;
 
 /* Message of the last failure on the calling thread ("" if none). */

@@ -475,7 +475,7 @@ struct rt_context {
     uint32_t work_used = 0;
     uint2 *d_batch = nullptr;       // frame colours of a batch
     size_t batch_capacity = 0;      // in frames
-    int tune_shade_num = 2, tune_leaf_lanes = 12, tune_blocks_per_cu = 0, tune_batch = 0, tune_sdone_lanes = 2, tune_refill_lanes = 4, tune_max_leaf = 4, tune_tri_cost_x10 = 12;
+    int tune_shade_num = 2, tune_leaf_lanes = 12, tune_blocks_per_cu = 0, tune_batch = 0, tune_sdone_lanes = 2, tune_refill_lanes = 4, tune_max_leaf = 4, tune_tri_cost_x10 = 12, tune_lds_state = RT_LDS_PARK;
 
     void free_scene()
     {
@@ -542,9 +542,9 @@ int launch_persistent_d(rt_context *c, const rt::FrameParams &fp, const BatchPar
     uint32_t depth = rt::kWideBvh ? c->host_scene.max_stack4 : c->host_scene.max_depth + 1;
     // 16-bit links: node indices below 32768 and leaf codes (first << 3 | count - 1) below 32768
     const rt::BuiltScene &hs = c->host_scene;
-    bool small = RT_LDS_PARK && hs.n_tris <= 4096 && hs.nodes.size() / 4 < 32768 && hs.nodes4.size() / 8 < 32768 && depth <= 32;
+    bool small = c->tune_lds_state >= 1 && hs.n_tris <= 4096 && hs.nodes.size() / 4 < 32768 && hs.nodes4.size() / 8 < 32768 && depth <= 32;
     if (small) {
-        if (depth <= RT_PARK2_STACK && RT_LDS_PARK >= 2) return launch_persistent_t<RT_PARK2_STACK, COUNT, FUSED, RT_PARK2_SLOTS>(c, fp, bp, counter);
+        if (depth <= RT_PARK2_STACK && c->tune_lds_state >= 2) return launch_persistent_t<RT_PARK2_STACK, COUNT, FUSED, RT_PARK2_SLOTS>(c, fp, bp, counter);
         return launch_persistent_t<32, COUNT, FUSED, 12>(c, fp, bp, counter);
     }
     if (depth <= 16) return launch_persistent_t<16, COUNT, FUSED, 0>(c, fp, bp, counter);
@@ -752,6 +752,7 @@ int rt_set_tuning(rt_context *c, int key, int value)
     case RT_TUNE_MAX_LEAF: if (value < 1 || value > 8) return fail(RT_ERR_INVALID, "max_leaf out of range"); c->tune_max_leaf = value; break;
     case RT_TUNE_TRI_COST_X10: if (value < 1 || value > 1000) return fail(RT_ERR_INVALID, "tri_cost out of range"); c->tune_tri_cost_x10 = value; break;
     case RT_TUNE_REFILL_LANES: if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "refill_lanes out of range"); c->tune_refill_lanes = value; break;
+    case RT_TUNE_LDS_STATE: if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "lds_state out of range"); c->tune_lds_state = value; break;
     case RT_TUNE_SHADOW_DONE_LANES: if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "shadow_done_lanes out of range"); c->tune_sdone_lanes = value; break;
     default: return fail(RT_ERR_INVALID, "unknown tuning key");
     }

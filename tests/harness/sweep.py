@@ -2,12 +2,12 @@
 import itertools, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from raytracer_amd import capi, scene as S
-name, W, H, spp, frames = "suzanne", 1920, 1080, 16, 8
+name, W, H, spp, frames = "suzanne", 1920, 1080, 16, 16
 sc = S.load_scene(S.scene_path(name))
 ctx = capi.Context(W, H)
 ctx.set_scene(S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles))
 ctx.set_uniforms(S.pack_uniforms(sc.camera, 1, W, H, spp))
-grid = list(itertools.product([1, 2, 3], [6, 8, 12], [1, 2, 4], [2, 4, 8]))
+grid = list(itertools.product([1, 2, 3, 4], [8, 12, 16, 24], [1, 2, 4, 8], [1, 4, 8, 16]))
 res = {g: [] for g in grid}
 for rnd in range(2):
     for g in grid:

@@ -33,7 +33,11 @@ class HarnessRenderer:
 
         self.S, self.scene, self.width, self.height = S, scene, width, height
         self.brute, self.max_bounces, self.max_leaf = brute, max_bounces, max_leaf
-        self.spheres, self.tris = S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles)
+        if isinstance(scene, tuple):  # (camera, packed spheres, packed triangles)
+            self.scene = S.Scene(camera=scene[0])
+            self.spheres, self.tris = scene[1], scene[2]
+        else:
+            self.spheres, self.tris = S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles)
         self.accum = np.zeros((3, height, width), np.float32)
         self.frame_f16 = np.zeros((height, width, 4), np.uint16)
         self.ids = np.zeros((height, width), np.int32)

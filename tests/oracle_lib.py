@@ -175,8 +175,12 @@ class OracleRenderer:
         self.width, self.height = width, height
         self.max_bounces = max_bounces
         self.threads = threads or (os.cpu_count() or 1)
-        self.spheres = S.pack_spheres(scene.spheres)
-        self.tris = S.pack_triangles(scene.triangles)
+        if isinstance(scene, tuple):  # (camera, packed spheres, packed triangles)
+            self.scene = S.Scene(camera=scene[0])
+            self.spheres, self.tris = scene[1], scene[2]
+        else:
+            self.spheres = S.pack_spheres(scene.spheres)
+            self.tris = S.pack_triangles(scene.triangles)
         self.rect = rect or (0, 0, width, height)
         self.frame_index = 0
         self.samples_per_pixel = 1

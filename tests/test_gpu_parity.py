@@ -19,16 +19,26 @@ def _f16_equal(a, b):
     return bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
 
 
-def run_pair(scene, width, height, frames, spp, mode, max_bounces=6):
+def _packed(scene):
+    """(camera, packed spheres, packed triangles) of a Scene or of such a tuple."""
+    if isinstance(scene, tuple):
+        return scene
+    return scene.camera, S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles)
+
+
+def run_pair(scene, width, height, frames, spp, mode, max_bounces=6, tuning=()):
     orc = O.OracleRenderer(scene, width, height, max_bounces=max_bounces)
     orc.set_samples_per_pixel(spp)
+    camera, spheres, triangles = _packed(scene)
     ctx = capi.Context(width, height)
     ctx.set_max_bounces(max_bounces)
     ctx.set_mode(mode)
-    ctx.set_scene(S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles))
+    for key, value in tuning:
+        ctx.set_tuning(key, value)
+    ctx.set_scene(spheres, triangles)
     for f in range(1, frames + 1):
         orc.render()
-        ctx.set_uniforms(S.pack_uniforms(scene.camera, f, width, height, spp))
+        ctx.set_uniforms(S.pack_uniforms(camera, f, width, height, spp))
         ctx.render_frame()
         ids = ctx.read_primary_ids()
         assert np.array_equal(ids, orc.ids), "primary ids differ in frame %d" % f
@@ -59,6 +69,13 @@ def test_config_a_spheres_640x360_16spp(scenes):
 
 def test_max_bounces_8(scenes):
     run_pair(scenes["boxes"], 96, 54, 2, 4, capi.RT_MODE_BVH, max_bounces=8)
+
+
+@pytest.mark.parametrize("lds_state", [0, 1, 2])
+def test_lane_state_placement_does_not_change_output(scenes, lds_state):
+    """Registers only / shadow-ray state in LDS / per-pixel state in LDS too: three kernel instantiations."""
+    run_pair(scenes["suzanne"], 100, 61, 2, 3, capi.RT_MODE_BVH, tuning=((capi.RT_TUNE_LDS_STATE, lds_state),))
+    run_batched(scenes["boxes"], 96, 54, 3, 4, 2, ((capi.RT_TUNE_LDS_STATE, lds_state),))
 
 
 def run_batched(scene, width, height, frames, spp, batch, tuning=(), stripes=None):
@@ -138,3 +155,19 @@ def test_heightfield_131k_triangles_bvh_vs_brute_force_on_gpu():
         assert _f16_equal(out[mode][1], ref[1])
         assert np.array_equal(out[mode][2], ref[2])
         assert out[mode][3] == ref[3]
+
+
+def test_subdivided_suzanne_62k_triangles_vs_oracle():
+    """The model's triangles split three times (61,966 triangles, part of them already under the
+    reference's determinant threshold), 8 bounces."""
+    from tests.synth import subdivided_suzanne_packed
+
+    run_pair(subdivided_suzanne_packed(3), 64, 36, 1, 2, capi.RT_MODE_BVH, max_bounces=8)
+
+
+def test_subdivided_suzanne_1m_triangles_vs_oracle():
+    """991,246 triangles (five splits), 8 bounces: the largest configuration, on an image the
+    brute-force oracle finishes in tens of seconds."""
+    from tests.synth import subdivided_suzanne_packed
+
+    run_pair(subdivided_suzanne_packed(5), 32, 18, 1, 1, capi.RT_MODE_BVH, max_bounces=8)
