@@ -13,7 +13,9 @@ dealt to the ranks in 8-row stripes; each rank renders K*N frames of its
 stripes (so the work per GPU is that of the N = 1 run: weak scaling), no
 collective on the data path, and one RCCL all-gather of the accumulator rows
 at the end, inside the timed region.  The assembled image is bit-identical to
-what one GPU renders for the same K*N frames.
+what one GPU renders for the same K*N frames.  ``--split frames`` deals the K*N
+frames instead (every rank renders whole images and sums them; one RCCL
+all-reduce of the sums at the end): same work per GPU, not bit-identical.
 
 Rank 0 prints one JSON line.  ``roofline`` prices the path-trace kernel against
 the FP32 vector peak (this path has no matrix work); ``cpu_baseline`` times the
@@ -46,6 +48,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU baseline band (0 = auto)")
+    ap.add_argument("--split", choices=["rows", "frames"], default="rows",
+                    help="N > 1: deal image rows (exact, default) or frames (sums + all-reduce) to the ranks")
     return ap.parse_args()
 
 
@@ -111,7 +115,11 @@ def main():
 
     scene = S.load_scene(S.scene_path(SCENE))
     spheres, tris = S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles)
-    ctx = capi.Context(WIDTH, HEIGHT, device=device, stripe_rows=8, stripe_index=rank, stripe_count=world)
+    by_frames = args.split == "frames" and use_dist
+    if by_frames:
+        ctx = capi.Context(WIDTH, HEIGHT, device=device)
+    else:
+        ctx = capi.Context(WIDTH, HEIGHT, device=device, stripe_rows=8, stripe_index=rank, stripe_count=world)
     ctx.set_max_bounces(MAX_BOUNCES)
     ctx.set_scene(spheres, tris)
     ctx.set_uniforms(S.pack_uniforms(scene.camera, 1, WIDTH, HEIGHT, SPP))
@@ -130,14 +138,31 @@ def main():
 
     # warmup (frames 1..W*frames_per_step); the timed run then restarts at frame 1
     if W > 0:
-        ctx.render_frames(1, W * frames_per_step)
+        if by_frames:
+            ctx.render_frame_sums(*sharding.frames_of_rank(1, W * frames_per_step, rank, world))
+        else:
+            ctx.render_frames(1, W * frames_per_step)
     barrier()
 
     c_before = [int(x) for x in ctx.read_counters()]
     barrier()
     t0 = time.perf_counter()
-    ctx.render_frames(1, K * frames_per_step)
-    if use_dist:
+    if by_frames:
+        # every rank: whole-image sums of its share of the frames; all-reduce; rank 0 keeps the result
+        ctx.clear_accum()
+        ctx.render_frame_sums(*sharding.frames_of_rank(1, K * frames_per_step, rank, world))
+        ctx.export_accum(local_rows.data_ptr())
+        ctx.sync()
+        total = sharding.all_reduce_sums(local_rows.cpu() if rehearse else local_rows)
+        if rank == 0:
+            total = total.cuda().contiguous()
+            torch.cuda.synchronize()
+            ctx.import_accum(total.data_ptr())
+            ctx.finish_frame_sums(K * frames_per_step)
+            ctx.sync()
+    else:
+        ctx.render_frames(1, K * frames_per_step)
+    if use_dist and not by_frames:
         # combine: every rank contributes its rows; rank 0 assembles the image
         ctx.export_owned_rows(local_rows.data_ptr())
         ctx.sync()
@@ -156,7 +181,18 @@ def main():
     rays = c_after[13] - c_before[13]        # rays actually traversed
     ray_calls = c_after[0] - c_before[0]     # ray_all calls as the reference counts them
 
-    if world > 1 and rank == 0 and os.environ.get("RT_BENCH_VERIFY") == "1":
+    if world > 1 and rank == 0 and os.environ.get("RT_BENCH_VERIFY") == "1" and by_frames:
+        ref = capi.Context(WIDTH, HEIGHT, device=device)
+        ref.set_max_bounces(MAX_BOUNCES)
+        ref.set_scene(spheres, tris)
+        ref.set_uniforms(S.pack_uniforms(scene.camera, 1, WIDTH, HEIGHT, SPP))
+        ref.render_frames(1, K * frames_per_step)
+        a, b = ref.read_accum(), ctx.read_accum()
+        ref.close()
+        d = np.abs(a - b)
+        print("verify: frame split vs single-GPU recurrence: %d of %d values differ by more than 1e-3 (clamped pixels), "
+              "median abs diff %.3g" % (int((d > 1e-3).sum()), d.size, float(np.median(d))), file=sys.stderr)
+    elif world > 1 and rank == 0 and os.environ.get("RT_BENCH_VERIFY") == "1":
         # the assembled image must equal what one GPU renders for the same frames (after the same warmup)
         ref = capi.Context(WIDTH, HEIGHT, device=device)
         ref.set_max_bounces(MAX_BOUNCES)
@@ -228,7 +264,9 @@ def main():
         "config": {
             "workload": "scene_suzanne.json 1920x1080, %d frames x %d spp, max bounces %d, BVH traversal%s"
                         % (K * frames_per_step, SPP, MAX_BOUNCES,
-                           "" if world == 1 else ", rows dealt to %d GPUs in 8-row stripes + RCCL all-gather" % world),
+                           "" if world == 1 else
+                           (", frames dealt to %d GPUs + RCCL all-reduce of the sums" % world if by_frames else
+                            ", rows dealt to %d GPUs in 8-row stripes + RCCL all-gather" % world)),
             "frames": K * frames_per_step,
             "spp_per_frame": SPP,
             "ms_per_frame": dt * 1e3 / (K * frames_per_step),

@@ -206,6 +206,32 @@ int rt_owned_rows(rt_context *ctx, int *rows);
 int rt_export_owned_rows(rt_context *ctx, void *dst_device);
 int rt_import_rows(rt_context *ctx, const void *src_device, int from_index);
 
+/*
+ * Frame-split rendering across GPUs (no counterpart in the reference).  Frames
+ * are dealt to ranks instead of rows: rank r of G renders frames first + r,
+ * first + r + G, ... of the whole image.  The accumulator recurrence
+ * (public/accumulator.wgsl:53-60) cannot run across ranks, so in this mode the
+ * planes collect the plain f32 sum of the frames' rgba16float colours; the
+ * ranks' sums are added (one all-reduce on the exported planes) and
+ * rt_finish_frame_sums turns the total into the accumulator value
+ * saturate(sum / (n_frames_total + 1)), which is what the recurrence yields
+ * for frames 1..n when no intermediate value is clamped.  Unlike the row
+ * split this is not bit-identical to a single-GPU run: the order of the f32
+ * additions differs and the per-frame saturate of pixels whose running mean
+ * exceeds 1 is skipped.
+ * rt_clear_accum: zero the planes (before the first rt_render_frame_sums).
+ * rt_render_frame_sums: trace n_frames frames first, first + stride, ... and
+ *   add their colours to the planes.
+ * rt_export_accum / rt_import_accum: copy the three full planes
+ *   (3*width*height float32, R plane, G plane, B plane) to / from device
+ *   memory on the context's GPU, on the context's stream.
+ */
+int rt_clear_accum(rt_context *ctx);
+int rt_render_frame_sums(rt_context *ctx, uint32_t first_frame_index, uint32_t n_frames, uint32_t stride);
+int rt_export_accum(rt_context *ctx, void *dst_device);
+int rt_import_accum(rt_context *ctx, const void *src_device);
+int rt_finish_frame_sums(rt_context *ctx, uint32_t n_frames_total);
+
 /* Acceleration-structure statistics of the current scene, for reports:
  * out[0] nodes, out[1] leaves, out[2] max depth, out[3] bytes on device. */
 int rt_scene_stats(rt_context *ctx, uint64_t out[4]);

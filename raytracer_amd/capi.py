@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -44,6 +45,11 @@ SYMBOLS = {
     "rt_owned_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "rt_export_owned_rows": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_import_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "rt_clear_accum": (C.c_int, [C.c_void_p]),
+    "rt_render_frame_sums": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rt_export_accum": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_import_accum": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_finish_frame_sums": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rt_scene_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 
@@ -55,6 +61,26 @@ class RtError(RuntimeError):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """A process can hold one HIP runtime.  PyTorch's wheel bundles its own libamdhip64 (same
+    soname as the system one); if the system copy gets loaded first, for librt_hip.so, torch later
+    finds no GPU.  So when torch is installed, load its copy first (without importing torch) and
+    let librt_hip.so bind to it.  RT_HIP_SYSTEM_RUNTIME=1 keeps the system runtime."""
+    if os.environ.get("RT_HIP_SYSTEM_RUNTIME") == "1" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except (ImportError, OSError):
+        pass
+
+
 def load():
     """Load librt_hip.so and declare every entry point."""
     global _lib
@@ -62,6 +88,7 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RtError("librt_hip.so is not built (run __graft_entry__.build() or make -C raytracer_amd/csrc)")
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name)
@@ -175,6 +202,21 @@ class Context:
 
     def import_rows(self, device_ptr: int, from_index: int):
         _check(self.lib.rt_import_rows(self.handle, C.c_void_p(device_ptr), from_index))
+
+    def clear_accum(self):
+        _check(self.lib.rt_clear_accum(self.handle))
+
+    def render_frame_sums(self, first_frame_index: int, n_frames: int, stride: int = 1):
+        _check(self.lib.rt_render_frame_sums(self.handle, first_frame_index, n_frames, stride))
+
+    def export_accum(self, device_ptr: int):
+        _check(self.lib.rt_export_accum(self.handle, C.c_void_p(device_ptr)))
+
+    def import_accum(self, device_ptr: int):
+        _check(self.lib.rt_import_accum(self.handle, C.c_void_p(device_ptr)))
+
+    def finish_frame_sums(self, n_frames_total: int):
+        _check(self.lib.rt_finish_frame_sums(self.handle, n_frames_total))
 
     def scene_stats(self) -> dict:
         out = np.zeros(4, dtype=np.uint64)

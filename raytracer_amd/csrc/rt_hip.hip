@@ -100,8 +100,10 @@ struct FrameBuffers {
 };
 
 // rgba16float store + accumulator.wgsl:44-68 for one pixel.
+// With `sum` the planes collect the plain f32 sum of the frames' rgba16float colours instead
+// (frame-split rendering: the division by the frame count happens after the ranks' sums are added).
 __device__ inline void store_pixel(const rt::FrameParams &fp, const FrameBuffers &fb, int px, int py, rt::f3 color,
-                                   int32_t primary_id)
+                                   int32_t primary_id, bool sum)
 {
     size_t p = (size_t)py * (size_t)fp.width + (size_t)px;
     size_t plane = (size_t)fp.width * (size_t)fp.height;
@@ -111,9 +113,16 @@ __device__ inline void store_pixel(const rt::FrameParams &fp, const FrameBuffers
     packed.y = (uint32_t)hb | (0x3c00u << 16);
     reinterpret_cast<uint2 *>(fb.frame_f16)[p] = packed;
     fb.ids[p] = primary_id;
-    fb.accum[p] = rt::accumulate_channel(fb.accum[p], rt::f16_bits_to_f32(hr), fp.frame_f);
-    fb.accum[plane + p] = rt::accumulate_channel(fb.accum[plane + p], rt::f16_bits_to_f32(hg), fp.frame_f);
-    fb.accum[2 * plane + p] = rt::accumulate_channel(fb.accum[2 * plane + p], rt::f16_bits_to_f32(hb), fp.frame_f);
+    float r = rt::f16_bits_to_f32(hr), g = rt::f16_bits_to_f32(hg), b = rt::f16_bits_to_f32(hb);
+    if (sum) {
+        fb.accum[p] += r;
+        fb.accum[plane + p] += g;
+        fb.accum[2 * plane + p] += b;
+    } else {
+        fb.accum[p] = rt::accumulate_channel(fb.accum[p], r, fp.frame_f);
+        fb.accum[plane + p] = rt::accumulate_channel(fb.accum[plane + p], g, fp.frame_f);
+        fb.accum[2 * plane + p] = rt::accumulate_channel(fb.accum[2 * plane + p], b, fp.frame_f);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -128,7 +137,7 @@ constexpr int kBlock = 256;
 
 template <bool BRUTE, int STACK, bool COUNT>
 __global__ __launch_bounds__(kBlock) void render_tiles_kernel(rt::SceneView sc, rt::FrameParams fp, StripeMap sm,
-                                                               int local_rows, FrameBuffers fb)
+                                                               int local_rows, FrameBuffers fb, bool sum)
 {
     __shared__ int32_t lds_stack[BRUTE ? 1 : STACK * kBlock];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void render_tiles_kernel(rt::SceneView sc, 
             stack.sp = 0;
             int32_t pid;
             rt::f3 color = rt::render_pixel<BRUTE>(sc, fp, px, py, stack, n_rays, pid, COUNT ? &cnt : nullptr);
-            store_pixel(fp, fb, px, py, color, pid);
+            store_pixel(fp, fb, px, py, color, pid, sum);
         }
     }
     uint32_t total = wave_sum(n_rays);
@@ -193,6 +202,8 @@ struct BatchParams {
     uint32_t first_frame; // frameIndex of batch frame 0
     uint32_t n_frames;
     uint2 *colors;        // [n_frames][local_rows * width] rgba16float bit patterns (unused when FUSED)
+    uint32_t stride;      // frameIndex step between batch frames (1, or the rank count when frames are dealt to ranks)
+    bool sum;             // accumulator planes collect plain sums of the frame colours
 };
 
 // PARK > 0: links fit 16 bits (<= 4096 triangles), so the stack uses 16-bit entries and the
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(kBlock, RT_MINW) void render_persistent_kernel(rt::
             int px = (int)((tile % tiles_x) * 8u + (slot & 7u));
             int ly = (int)((tile / tiles_x) * 8u + (slot >> 3));
             int py = stripe_global_row(sm, ly);
-            if (FUSED) store_pixel(fp, fb, px, py, color, rt::lane_primary_id(park));
+            if (FUSED) store_pixel(fp, fb, px, py, color, rt::lane_primary_id(park), bp.sum);
             else {
                 size_t lp = (size_t)ly * fp.width + px;
                 uint2 packed;
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(kBlock, RT_MINW) void render_persistent_kernel(rt::
                             rt::lane_empty_pixel(L, park);
                         } else {
                             rt::FrameParams f = fp;
-                            if (!FUSED) f.seed_add = (uint32_t)(float)(bp.first_frame + frame_k) * 12345u;
+                            if (!FUSED) f.seed_add = (uint32_t)(float)(bp.first_frame + frame_k * bp.stride) * 12345u;
                             rt::lane_begin_pixel(sc, f, L, px, py, stack, park, n_rays, cp);
                         }
                     }
@@ -383,15 +394,29 @@ __global__ void accumulate_batch_kernel(FrameBuffers fb, BatchParams bp, int wid
     uint2 packed = make_uint2(0u, 0u);
     for (uint32_t k = 0; k < bp.n_frames; k++) {
         packed = bp.colors[(size_t)k * n + i];
-        float frame_f = (float)(bp.first_frame + k);
-        r = rt::accumulate_channel(r, rt::f16_bits_to_f32((uint16_t)(packed.x & 0xffffu)), frame_f);
-        g = rt::accumulate_channel(g, rt::f16_bits_to_f32((uint16_t)(packed.x >> 16)), frame_f);
-        b = rt::accumulate_channel(b, rt::f16_bits_to_f32((uint16_t)(packed.y & 0xffffu)), frame_f);
+        float frame_f = (float)(bp.first_frame + k * bp.stride);
+        float cr = rt::f16_bits_to_f32((uint16_t)(packed.x & 0xffffu)), cg = rt::f16_bits_to_f32((uint16_t)(packed.x >> 16)),
+              cb = rt::f16_bits_to_f32((uint16_t)(packed.y & 0xffffu));
+        if (bp.sum) {
+            r += cr; g += cg; b += cb;
+        } else {
+            r = rt::accumulate_channel(r, cr, frame_f);
+            g = rt::accumulate_channel(g, cg, frame_f);
+            b = rt::accumulate_channel(b, cb, frame_f);
+        }
     }
     fb.accum[p] = r;
     fb.accum[plane + p] = g;
     fb.accum[2 * plane + p] = b;
     reinterpret_cast<uint2 *>(fb.frame_f16)[p] = packed;
+}
+
+// planes := saturate(planes / divisor): closes a frame-split render (accumulator.wgsl:57-60 for
+// the whole sum at once).
+__global__ void finish_sums_kernel(float *planes, size_t n, float divisor)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) planes[i] = fminf(fmaxf(planes[i] / divisor, 0.0f), 1.0f);
 }
 
 __global__ void fill_i32_kernel(int32_t *p, int32_t v, size_t n)
@@ -491,7 +516,7 @@ constexpr uint32_t kWorkCounters = 4096;
 constexpr size_t kBatchBytesCap = (size_t)1 << 30;
 constexpr uint64_t kUnitsPerLaunch = 16ull * 1920 * 1080;
 
-int launch_tiles(rt_context *c, const rt::FrameParams &fp)
+int launch_tiles(rt_context *c, const rt::FrameParams &fp, bool sum)
 {
     dim3 block(kBlock);
     dim3 grid((c->width + 31) / 32, (c->local_rows + 7) / 8);
@@ -499,7 +524,7 @@ int launch_tiles(rt_context *c, const rt::FrameParams &fp)
     uint32_t depth = c->host_scene.max_depth;
 #define RT_LAUNCH_A(BRUTE, STACK, COUNT)                                                                        \
     hipLaunchKernelGGL((render_tiles_kernel<BRUTE, STACK, COUNT>), grid, block, 0, c->stream, c->view, fp, c->sm, \
-                       c->local_rows, c->fb)
+                       c->local_rows, c->fb, sum)
     if (c->mode == RT_MODE_BRUTE_FORCE) {
         RT_LAUNCH_A(true, 1, false);
     } else if (c->counting) {
@@ -553,8 +578,8 @@ int launch_persistent_d(rt_context *c, const rt::FrameParams &fp, const BatchPar
     return fail(RT_ERR_UNSUPPORTED, "acceleration structure too deep for the traversal stack");
 }
 
-// Frames first .. first + n - 1 through the persistent kernel, in batches.
-int launch_persistent(rt_context *c, uint32_t first, uint32_t n)
+// Frames first, first + stride, ... (n of them) through the persistent kernel, in batches.
+int launch_persistent(rt_context *c, uint32_t first, uint32_t n, uint32_t stride, bool sum)
 {
     size_t local_px = (size_t)c->local_rows * c->width;
     if (local_px == 0 || n == 0) return RT_OK;
@@ -574,11 +599,11 @@ int launch_persistent(rt_context *c, uint32_t first, uint32_t n)
         if (c->work_used == 0) RT_HIP_CHECK(hipMemsetAsync(c->d_work, 0, kWorkCounters * sizeof(unsigned int), c->stream));
         unsigned int *counter = c->d_work + c->work_used;
         c->work_used = (c->work_used + 1) % kWorkCounters;
-        c->uniforms[12] = (float)(first + done);
+        c->uniforms[12] = (float)(first + done * stride);
         rt::FrameParams fp;
         std::string err;
         if (!rt::make_frame_params(c->uniforms, c->max_bounces, fp, err)) return fail(RT_ERR_INVALID, err);
-        BatchParams bp{first + done, b, nullptr};
+        BatchParams bp{first + done * stride, b, nullptr, stride, sum};
         int rc;
         if (b == 1) {
             rc = c->counting ? launch_persistent_d<true, true>(c, fp, bp, counter) : launch_persistent_d<false, true>(c, fp, bp, counter);
@@ -598,7 +623,7 @@ int launch_persistent(rt_context *c, uint32_t first, uint32_t n)
         }
         done += b;
     }
-    c->uniforms[12] = (float)(first + n - 1);
+    c->uniforms[12] = (float)(first + (n - 1) * stride);
     return RT_OK;
 }
 
@@ -759,25 +784,75 @@ int rt_set_tuning(rt_context *c, int key, int value)
     return RT_OK;
 }
 
-int rt_render_frames(rt_context *c, uint32_t first_frame_index, uint32_t n_frames)
+static int render_frames_impl(rt_context *c, uint32_t first_frame_index, uint32_t n_frames, uint32_t stride, bool sum)
 {
     int rc = check_ready(c);
     if (rc) return rc;
+    if (stride < 1) return fail(RT_ERR_INVALID, "frame stride must be at least 1");
+    if (n_frames && (uint64_t)first_frame_index + (uint64_t)(n_frames - 1) * stride >= (1ull << 24))
+        return fail(RT_ERR_INVALID, "frame index beyond 2^24 is not exact in the f32 uniform");
     RT_HIP_CHECK(hipSetDevice(c->device));
     RT_HIP_CHECK(hipEventRecord(c->ev_start, c->stream));
     if (c->mode == RT_MODE_BVH) {
-        if ((rc = launch_persistent(c, first_frame_index, n_frames))) return rc;
+        if ((rc = launch_persistent(c, first_frame_index, n_frames, stride, sum))) return rc;
     } else {
         for (uint32_t k = 0; k < n_frames; k++) {
-            c->uniforms[12] = (float)(first_frame_index + k);
+            c->uniforms[12] = (float)(first_frame_index + k * stride);
             rt::FrameParams fp;
             std::string err;
             if (!rt::make_frame_params(c->uniforms, c->max_bounces, fp, err)) return fail(RT_ERR_INVALID, err);
-            if ((rc = launch_tiles(c, fp))) return rc;
+            if ((rc = launch_tiles(c, fp, sum))) return rc;
         }
     }
     RT_HIP_CHECK(hipEventRecord(c->ev_stop, c->stream));
     c->timed = true;
+    return RT_OK;
+}
+
+int rt_render_frames(rt_context *c, uint32_t first_frame_index, uint32_t n_frames)
+{
+    return render_frames_impl(c, first_frame_index, n_frames, 1, false);
+}
+
+int rt_render_frame_sums(rt_context *c, uint32_t first_frame_index, uint32_t n_frames, uint32_t stride)
+{
+    return render_frames_impl(c, first_frame_index, n_frames, stride, true);
+}
+
+int rt_clear_accum(rt_context *c)
+{
+    if (!c) return fail(RT_ERR_INVALID, "null context");
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    RT_HIP_CHECK(hipMemsetAsync(c->fb.accum, 0, (size_t)c->width * c->height * 3 * sizeof(float), c->stream));
+    return RT_OK;
+}
+
+int rt_export_accum(rt_context *c, void *dst_device)
+{
+    if (!c || !dst_device) return fail(RT_ERR_INVALID, "null argument");
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    RT_HIP_CHECK(hipMemcpyAsync(dst_device, c->fb.accum, (size_t)c->width * c->height * 3 * sizeof(float),
+                                hipMemcpyDeviceToDevice, c->stream));
+    return RT_OK;
+}
+
+int rt_import_accum(rt_context *c, const void *src_device)
+{
+    if (!c || !src_device) return fail(RT_ERR_INVALID, "null argument");
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    RT_HIP_CHECK(hipMemcpyAsync(c->fb.accum, src_device, (size_t)c->width * c->height * 3 * sizeof(float),
+                                hipMemcpyDeviceToDevice, c->stream));
+    return RT_OK;
+}
+
+int rt_finish_frame_sums(rt_context *c, uint32_t n_frames_total)
+{
+    if (!c) return fail(RT_ERR_INVALID, "null context");
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    size_t n = (size_t)c->width * c->height * 3;
+    hipLaunchKernelGGL(finish_sums_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->fb.accum, n,
+                       (float)n_frames_total + 1.0f);
+    RT_HIP_CHECK(hipGetLastError());
     return RT_OK;
 }
 

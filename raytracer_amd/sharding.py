@@ -1,5 +1,5 @@
-"""Image-row sharding across GPUs: which rows a rank renders and how the
-accumulator rows are combined afterwards.
+"""Sharding across GPUs: by image rows (exact) or by frames (approximate), and how
+the accumulator is combined afterwards.
 
 The reference renders on one GPU.  A pixel's value depends only on
 (x, y, width, frameIndex) and the replicated scene
@@ -9,6 +9,14 @@ finished accumulator rows.  Rows are dealt in 8-row stripes (the height of the
 8x8 pixel tiles the kernel works in), round-robin, which balances cheap sky
 rows and expensive rows: rank r owns row y iff (y // stripe_rows) % world == r.
 This is the rule rt_create implements natively (include/rt_hip.h).
+
+The frame split deals frames instead: rank r renders frames first + r,
+first + r + world, ... of the whole image and keeps the plain f32 sum of their
+rgba16float colours; one all-reduce adds the sums and
+saturate(sum / (n_frames + 1)) stands in for the accumulator recurrence
+(public/accumulator.wgsl:53-60).  It suits scenes so heavy that a frame should
+stay on one GPU; it is not bit-identical to a single-GPU run (addition order,
+no per-frame clamp of pixels whose running mean exceeds 1).
 """
 from __future__ import annotations
 
@@ -54,3 +62,26 @@ def assemble(blocks: List[np.ndarray], height: int, width: int, stripe_rows: int
         assert block.shape == (3, len(rows), width), (block.shape, len(rows))
         full[:, rows, :] = block
     return full
+
+
+def frames_of_rank(first: int, n_frames: int, rank: int, world: int):
+    """(first frame, frame count, stride) of `rank` when frames first .. first + n_frames - 1
+    are dealt round-robin: frame k goes to rank (k - first) % world."""
+    count = (n_frames - rank + world - 1) // world if n_frames > rank else 0
+    return first + rank, count, world
+
+
+def all_reduce_sums(planes):
+    """In-place sum over ranks of the (3, height, width) float32 planes (torch tensor on the
+    process group's device)."""
+    import torch.distributed as dist
+
+    dist.all_reduce(planes, op=dist.ReduceOp.SUM)
+    return planes
+
+
+def finish_sums(sums: np.ndarray, n_frames: int) -> np.ndarray:
+    """Accumulator value of frames 1..n_frames from the sum of their colours (host-side
+    counterpart of rt_finish_frame_sums)."""
+    mean = sums.astype(np.float32) / np.float32(n_frames + 1)
+    return np.fmin(np.fmax(mean, np.float32(0)), np.float32(1)).astype(np.float32)  # NaN -> 0, as the kernel's saturate

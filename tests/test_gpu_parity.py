@@ -171,3 +171,55 @@ def test_subdivided_suzanne_1m_triangles_vs_oracle():
     from tests.synth import subdivided_suzanne_packed
 
     run_pair(subdivided_suzanne_packed(5), 32, 18, 1, 1, capi.RT_MODE_BVH, max_bounces=8)
+
+
+def test_frame_split_sums_match_the_recurrence(scenes):
+    """Two contexts stand in for two ranks: each sums its share of the frames, the sums are
+    added on the device (what the all-reduce does) and finished; against the oracle's sequential
+    accumulator the result differs by rounding only, except where the recurrence clamps."""
+    import torch
+
+    scene = scenes["boxes"]
+    width, height, frames, spp, world = 96, 54, 5, 2, 2
+    from raytracer_amd import sharding
+
+    orc = O.OracleRenderer(scene, width, height)
+    orc.set_samples_per_pixel(spp)
+    exact = np.zeros((3, height, width), np.float64)
+    clamped = np.zeros((height, width), bool)   # pixels whose running mean left [0, 1] at some frame (or is NaN)
+    for f in range(1, frames + 1):
+        before = orc.accum.copy()
+        orc.render()
+        cur = np.transpose(orc.frame_f16.view(np.float16).astype(np.float32)[:, :, :3], (2, 0, 1))
+        exact += cur
+        w = np.float32(1) / np.float32(f + 1)
+        clamped |= ~((before * (np.float32(1) - w) + cur * w >= 0) & (before * (np.float32(1) - w) + cur * w <= 1)).all(axis=0)
+    total = torch.zeros((3, height, width), dtype=torch.float32, device="cuda")
+    ctxs = []
+    for rank in range(world):
+        ctx = capi.Context(width, height)
+        ctx.set_scene(S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles))
+        ctx.set_uniforms(S.pack_uniforms(scene.camera, 1, width, height, spp))
+        ctx.set_tuning(capi.RT_TUNE_BATCH_FRAMES, 2)   # rank 0 has three frames: a batch of two and a single
+        first, count, stride = sharding.frames_of_rank(1, frames, rank, world)
+        ctx.clear_accum()
+        ctx.render_frame_sums(first, count, stride)
+        part = torch.empty_like(total)
+        torch.cuda.synchronize()
+        ctx.export_accum(part.data_ptr())
+        ctx.sync()
+        total += part
+        torch.cuda.synchronize()   # the contexts write on their own streams: nothing of torch's may be in flight
+        ctxs.append(ctx)
+    sums = total.cpu().numpy()
+    finite = np.isfinite(exact)
+    assert np.array_equal(np.isfinite(sums), finite)
+    assert np.abs(sums - exact)[finite].max() <= 1e-5 * max(1.0, np.abs(exact[finite]).max())
+    ctxs[0].import_accum(total.data_ptr())
+    ctxs[0].finish_frame_sums(frames)
+    got = np.transpose(ctxs[0].read_accum(), (2, 0, 1))
+    assert np.array_equal(got, sharding.finish_sums(sums, frames), equal_nan=True)
+    diff = np.abs(got - orc.accum)
+    assert diff[:, ~clamped].max() <= 2e-6
+    for ctx in ctxs:
+        ctx.close()

@@ -72,3 +72,64 @@ def test_two_rank_gloo_gather_is_bit_identical(tmp_path):
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "SHARD_OK" in out.stdout
+
+
+FRAME_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from raytracer_amd import scene as S, sharding
+from tests import oracle_lib as O
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+W, H, frames, spp = 48, 27, 5, 2
+sc = S.load_scene(S.scene_path("boxes"))
+first, count, stride = sharding.frames_of_rank(1, frames, rank, world)
+sums = np.zeros((3, H, W), np.float32)
+orc = O.OracleRenderer(sc, W, H); orc.set_samples_per_pixel(spp)
+for k in range(count):
+    orc.frame_index = first + k * stride - 1      # render() pre-increments
+    orc.render()
+    f = orc.frame_f16.view(np.float16).astype(np.float32)
+    sums += np.transpose(f[:, :, :3], (2, 0, 1))
+t = torch.from_numpy(sums)
+sharding.all_reduce_sums(t)
+if rank == 0:
+    got = sharding.finish_sums(t.numpy(), frames)
+    ref = O.OracleRenderer(sc, W, H); ref.set_samples_per_pixel(spp)
+    clamped = np.zeros((H, W), bool)    # pixels whose running mean left [0, 1] at some frame (or is NaN)
+    for f in range(1, frames + 1):
+        before = ref.accum.copy()
+        ref.render()
+        cur = np.transpose(ref.frame_f16.view(np.float16).astype(np.float32)[:, :, :3], (2, 0, 1))
+        w = np.float32(1) / np.float32(f + 1)
+        raw = before * (np.float32(1) - w) + cur * w
+        clamped |= ~((raw >= 0) & (raw <= 1)).all(axis=0)
+    diff = np.abs(got - ref.accum)
+    assert diff[:, ~clamped].max() <= 2e-6, diff[:, ~clamped].max()
+    print("FRAME_SPLIT_OK", float(diff[:, ~clamped].max()), int(clamped.sum()))
+dist.destroy_process_group()
+'''
+
+
+def test_frames_of_rank_deals_every_frame_once():
+    for first, n, world in [(1, 5, 2), (1, 64, 8), (7, 3, 4), (1, 1, 8), (1, 0, 2)]:
+        seen = []
+        for r in range(world):
+            f0, count, stride = sharding.frames_of_rank(first, n, r, world)
+            seen += [f0 + k * stride for k in range(count)]
+        assert sorted(seen) == list(range(first, first + n))
+
+
+def test_two_rank_gloo_frame_split_matches_recurrence(tmp_path):
+    script = tmp_path / "frame_worker.py"
+    script.write_text(FRAME_WORKER % {"root": ROOT})
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "FRAME_SPLIT_OK" in out.stdout
