@@ -64,10 +64,12 @@ def cpu_baseline(scene, threads):
         orc.render()
         return int(orc.counters[0]), time.perf_counter() - t
 
-    # warm up (library load, thread start), calibrate on 2 rows, then size the band for about 15 s
+    # warm up (library load, thread start), calibrate on one row per thread (the oracle splits a band
+    # into rows), then size the band for about 15 s
     run(540, 541)
-    rays, dt = run(540, 542)
-    rows = int(max(2, min(HEIGHT // 2, round(2 * 15.0 / max(dt, 1e-3)))))
+    cal = max(2, min(threads, 64))
+    rays, dt = run(540 - cal // 2, 540 - cal // 2 + cal)
+    rows = int(max(cal, min(HEIGHT // 2, round(cal * 15.0 / max(dt, 1e-3)))))
     y0 = (HEIGHT - rows) // 2
     rays, dt = run(y0, y0 + rows)
     return {

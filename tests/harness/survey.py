@@ -3,10 +3,12 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from raytracer_amd import capi, scene as S
 from tests.synth import heightfield_scene
+from tests.synth import subdivided_suzanne_packed
 def run(label, sc, W, H, frames, spp, bounces=6):
     ctx = capi.Context(W, H); ctx.set_max_bounces(bounces)
-    t = time.time(); ctx.set_scene(S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles)); tb = time.time() - t
-    ctx.set_uniforms(S.pack_uniforms(sc.camera, 1, W, H, spp))
+    cam, sp, tr = sc if isinstance(sc, tuple) else (sc.camera, S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles))
+    t = time.time(); ctx.set_scene(sp, tr); tb = time.time() - t
+    ctx.set_uniforms(S.pack_uniforms(cam, 1, W, H, spp))
     ctx.render_frames(1, 2); ctx.sync()
     c0 = ctx.read_counters()
     ctx.render_frames(1, frames); ctx.sync(); ms = ctx.last_render_ms()
@@ -18,6 +20,8 @@ L = lambda n: S.load_scene(S.scene_path(n))
 run("(a) spheres", L("spheres"), 640, 360, 16, 16)
 run("(b) boxes 64 spp", L("boxes"), 1920, 1080, 4, 16)
 run("(c) suzanne 256 spp", L("suzanne"), 1920, 1080, 16, 16)
-run("(c') suzanne 16 x 1 spp", L("suzanne"), 1920, 1080, 16, 1)
+run("(c') suzanne 256 x 1 spp", L("suzanne"), 1920, 1080, 256, 1)
+run("(b') boxes 64 x 1 spp", L("boxes"), 1920, 1080, 64, 1)
 run("(d) suzanne 4K 1 GPU", L("suzanne"), 3840, 2160, 16, 16)
 run("heightfield 131k tris, 8 b", heightfield_scene(256), 1920, 1080, 4, 16, 8)
+run("(e) suzanne split 5x, 991k", subdivided_suzanne_packed(5), 1920, 1080, 8, 16, 8)
