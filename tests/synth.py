@@ -55,3 +55,49 @@ def subdivided_suzanne_packed(levels: int):
     out = np.repeat(model[:1], len(v), axis=0)
     out[:, 0:3], out[:, 4:7], out[:, 8:11] = v[:, 0], v[:, 1], v[:, 2]
     return base.camera, S.pack_spheres(base.spheres), np.concatenate([room, out], axis=0)
+
+
+def edge_scenes() -> dict:
+    """Scenes that exercise what the reference's three scene files do not: empty inputs, no
+    lights, emissive and specular spheres, a rotated camera, coincident and degenerate
+    triangles, many spheres.  Built from scene_boxes / scene_spheres data, no random numbers."""
+    import copy
+
+    boxes = S.load_scene(S.scene_path("boxes"))
+    spheres = S.load_scene(S.scene_path("spheres"))
+    out = {}
+    out["empty"] = S.Scene(camera=boxes.camera)
+    out["spheres_only"] = S.Scene(camera=spheres.camera, spheres=spheres.spheres)
+    out["no_lights"] = S.Scene(camera=boxes.camera, spheres=boxes.spheres,
+                               triangles=[t for t in boxes.triangles if not t["emissionStrength"] > 0])
+    cam = copy.deepcopy(spheres.camera)
+    cam["rotation"] = [12.0, -25.0, 0.0]
+    cam["position"] = [1.5, 2.2, 4.0]
+    out["rotated_camera"] = S.Scene(camera=cam, spheres=spheres.spheres, triangles=spheres.triangles)
+    cam = copy.deepcopy(spheres.camera)
+    cam["rotation"] = [-89.5, 181.0, 7.0]      # looks almost straight down; roll component is ignored by the shader
+    cam["position"] = [0.0, 4.5, -2.5]
+    cam["fov"] = 75
+    out["camera_down"] = S.Scene(camera=cam, spheres=spheres.spheres, triangles=spheres.triangles)
+    sp = copy.deepcopy(spheres.spheres)
+    sp[0].update(emissionColor=[1.0, 0.6, 0.2], emissionStrength=3.0)
+    sp[1].update(smoothness=1.0, specularProbability=1.0)
+    out["emissive_and_mirror_spheres"] = S.Scene(camera=spheres.camera, spheres=sp, triangles=spheres.triangles)
+    # every triangle twice (the first copy must win every tie), plus zero-area and needle triangles
+    tris = []
+    for t in boxes.triangles:
+        tris += [t, copy.deepcopy(t)]
+    tris.append(dict(boxes.triangles[0], v0=[0, 1, -2], v1=[0, 1, -2], v2=[0, 1, -2]))
+    tris.append(dict(boxes.triangles[0], v0=[-1, 1, -2], v1=[0, 1, -2], v2=[1, 1, -2]))
+    tris.append(dict(boxes.triangles[0], v0=[-1, 0.5, -2], v1=[1, 0.5, -2], v2=[0, 0.5004, -2]))
+    out["duplicates_and_degenerates"] = S.Scene(camera=boxes.camera, spheres=boxes.spheres, triangles=tris)
+    many = []
+    for k in range(24):
+        many.append(dict(center=[-2.0 + 0.35 * (k % 12), 0.3 + 0.9 * (k // 12), -2.0 - 0.15 * k], radius=0.16 + 0.01 * (k % 5),
+                         color=[0.3 + 0.05 * (k % 7), 0.8 - 0.03 * k, 0.4], smoothness=0.1 * (k % 10),
+                         emissionColor=[1, 1, 1], emissionStrength=2.0 if k == 5 else 0.0,
+                         specularProbability=0.05 * (k % 20)))
+    # two coincident spheres: the lower index must be reported
+    many.append(copy.deepcopy(many[3]))
+    out["many_spheres"] = S.Scene(camera=boxes.camera, spheres=many, triangles=boxes.triangles)
+    return out

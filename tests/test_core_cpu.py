@@ -69,3 +69,43 @@ def test_lane_state_machine_matches_oracle(scenes, name, width, height, frames, 
     assert np.array_equal(har.frame_f16, orc.frame_f16)
     assert np.array_equal(har.accum, orc.accum)
     assert int(har.counters[0]) == int(orc.counters[0])
+
+
+EDGE_CASES = ["empty", "spheres_only", "no_lights", "rotated_camera", "camera_down", "emissive_and_mirror_spheres",
+              "duplicates_and_degenerates", "many_spheres"]
+
+
+@pytest.mark.parametrize("name", EDGE_CASES)
+def test_edge_scenes_match_oracle(name):
+    from tests.synth import edge_scenes
+
+    scene = edge_scenes()[name]
+    compare(scene, 72, 41, 2, 3, False)
+    orc = O.OracleRenderer(scene, 40, 23)
+    orc.set_samples_per_pixel(2)
+    orc.render_frames(2)
+    har = HarnessRenderer(scene, 40, 23)
+    har.render_frames_lanes(2, 1, 2)
+    assert np.array_equal(har.ids, orc.ids)
+    assert np.array_equal(har.frame_f16, orc.frame_f16)
+    assert np.array_equal(har.accum, orc.accum)
+
+
+@pytest.mark.parametrize("width,height", [(1, 1), (1, 9), (9, 1), (8, 8), (65, 3)])
+def test_tiny_and_thin_images(scenes, width, height):
+    compare(scenes["boxes"], width, height, 2, 2, False)
+
+
+def test_late_frame_indices(scenes):
+    """frameIndex 1000..1001: the seed offset frameIndex * 12345 and the weight 1/(frameIndex+1)."""
+    scene = scenes["spheres"]
+    orc = O.OracleRenderer(scene, 48, 27)
+    orc.set_samples_per_pixel(2)
+    orc.frame_index = 999
+    orc.render_frames(2)
+    har = HarnessRenderer(scene, 48, 27)
+    har.frame_index = 999
+    har.render(2)
+    har.render(2)
+    assert np.array_equal(har.frame_f16, orc.frame_f16)
+    assert np.array_equal(har.accum, orc.accum)

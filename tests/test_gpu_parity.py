@@ -223,3 +223,70 @@ def test_frame_split_sums_match_the_recurrence(scenes):
     assert diff[:, ~clamped].max() <= 2e-6
     for ctx in ctxs:
         ctx.close()
+
+
+@pytest.mark.parametrize("name", ["empty", "spheres_only", "no_lights", "rotated_camera", "camera_down",
+                                  "emissive_and_mirror_spheres", "duplicates_and_degenerates", "many_spheres"])
+def test_edge_scenes_bit_exact(name):
+    """Empty inputs, no lights, rotated cameras, emissive / mirror spheres, coincident and degenerate
+    triangles, a long sphere list: single frames (fused epilogue) and a batch, all modes for the first."""
+    from tests.synth import edge_scenes
+
+    scene = edge_scenes()[name]
+    for mode in (capi.RT_MODE_BVH, capi.RT_MODE_BVH_TILES, capi.RT_MODE_BRUTE_FORCE):
+        run_pair(scene, 72, 41, 2, 3, mode)
+    run_batched(scene, 72, 41, 3, 2, 3)
+
+
+@pytest.mark.parametrize("width,height", [(1, 1), (1, 9), (9, 1), (8, 8), (65, 3)])
+def test_tiny_and_thin_images(scenes, width, height):
+    run_pair(scenes["boxes"], width, height, 2, 2, capi.RT_MODE_BVH)
+    run_batched(scenes["boxes"], width, height, 3, 2, 2)
+
+
+def test_late_frame_indices_and_reset(scenes):
+    """frameIndex 1000..1002 in one batch (seed offset and weights), then resetAccumulation's effect:
+    frameIndex back to 1 with the planes kept (src/webgpu-renderer.ts:274-276)."""
+    scene = scenes["spheres"]
+    width, height, spp = 48, 27, 2
+    orc = O.OracleRenderer(scene, width, height)
+    orc.set_samples_per_pixel(spp)
+    orc.frame_index = 999
+    orc.render_frames(3)
+    ctx = capi.Context(width, height)
+    ctx.set_scene(S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles))
+    ctx.set_uniforms(S.pack_uniforms(scene.camera, 1000, width, height, spp))
+    ctx.render_frames(1000, 3)
+    assert np.array_equal(ctx.read_accum(), orc.accum_rgb())
+    orc.reset_accumulation()
+    orc.render_frames(2)
+    ctx.render_frames(1, 2)
+    assert _f16_equal(ctx.read_frame_f16(), orc.frame_f16)
+    assert np.array_equal(ctx.read_accum(), orc.accum_rgb())
+    ctx.close()
+
+
+def test_invalid_arguments_are_rejected(scenes):
+    scene = scenes["spheres"]
+    ctx = capi.Context(16, 9)
+    with pytest.raises(capi.RtError):
+        ctx.render_frame()                      # no scene yet
+    ctx.set_scene(S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles))
+    with pytest.raises(capi.RtError):
+        ctx.render_frame()                      # no uniforms yet
+    with pytest.raises(capi.RtError):
+        ctx.set_uniforms(S.pack_uniforms(scene.camera, 1, 32, 9, 1))   # resolution differs from the context's
+    with pytest.raises(capi.RtError):
+        ctx.set_max_bounces(256)
+    with pytest.raises(capi.RtError):
+        ctx.set_tuning(99, 1)
+    with pytest.raises(capi.RtError):
+        ctx.set_mode(7)
+    ctx.set_uniforms(S.pack_uniforms(scene.camera, 1, 16, 9, 1))
+    ctx.render_frame()
+    ctx.sync()
+    ctx.close()
+    with pytest.raises(capi.RtError):
+        capi.Context(0, 9)
+    with pytest.raises(capi.RtError):
+        capi.Context(16, 9, stripe_index=2, stripe_count=2)

@@ -42,7 +42,18 @@ def test_primitives_agree(scenes):
     ("boxes", 16, 9, 1, 3),
 ])
 def test_frames_agree(scenes, name, width, height, frames, spp):
-    sc = scenes[name]
+    _frames_agree(scenes[name], width, height, frames, spp)
+
+
+@pytest.mark.parametrize("name", ["rotated_camera", "camera_down", "emissive_and_mirror_spheres", "many_spheres", "empty"])
+def test_edge_scene_frames_agree(name):
+    """Camera rotation, emissive and mirror spheres, many spheres: paths the reference's scene files never take."""
+    from tests.synth import edge_scenes
+
+    _frames_agree(edge_scenes()[name], 16, 9, 1, 2)
+
+
+def _frames_agree(sc, width, height, frames, spp):
     spheres, tris = S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles)
     orc = O.OracleRenderer(sc, width, height)
     orc.set_samples_per_pixel(spp)
