@@ -54,7 +54,10 @@ __host__ __device__ inline int stripe_global_row(const StripeMap &m, int local)
 #define RT_PARK2_STACK 24
 #endif
 #ifndef RT_PARK2_SLOTS
-#define RT_PARK2_SLOTS 17
+#define RT_PARK2_SLOTS 14
+#endif
+#ifndef RT_PARK2_MINW
+#define RT_PARK2_MINW 6
 #endif
 
 template <int BLOCK, class Entry>
@@ -132,7 +135,7 @@ __device__ inline void store_pixel(const rt::FrameParams &fp, const FrameBuffers
 // ---------------------------------------------------------------------------
 constexpr int kBlock = 256;
 #ifndef RT_MINW
-#define RT_MINW 5 // waves per SIMD the persistent kernel is compiled for (<= 96 VGPRs; measured best)
+#define RT_MINW 5 // waves per SIMD the persistent kernel is compiled for when lane state stays in registers (<= 96 VGPRs)
 #endif
 
 template <bool BRUTE, int STACK, bool COUNT>
@@ -208,11 +211,12 @@ struct BatchParams {
 
 // PARK > 0: links fit 16 bits (<= 4096 triangles), so the stack uses 16-bit entries and the
 // room saved in LDS holds the first PARK slots of the lanes' rarely touched state (12: what is
-// set aside during shadow rays; 17: the per-pixel radiance sum and primary hit too).  PARK == 0:
-// 32-bit entries, all state in registers.  STACK * sizeof(entry) + PARK * 4 must stay below
-// 128 bytes per lane: at exactly 32 KB per block only four blocks fit a CU.
-template <int STACK, bool COUNT, bool FUSED, int PARK>
-__global__ __launch_bounds__(kBlock, RT_MINW) void render_persistent_kernel(rt::SceneView sc, rt::FrameParams fp, StripeMap sm,
+// set aside during shadow rays; more: per-pixel values too).  PARK == 0: 32-bit entries, all
+// state in registers.  MINW = waves per SIMD the instantiation is compiled for: 6 (80 VGPRs)
+// needs STACK * sizeof(entry) + PARK * 4 <= 104 bytes per lane (26 KB per block, six blocks in
+// a CU's 160 KB), 5 (96 VGPRs) needs it below 128 (at exactly 32 KB only four blocks fit).
+template <int STACK, bool COUNT, bool FUSED, int PARK, int MINW>
+__global__ __launch_bounds__(kBlock, MINW) void render_persistent_kernel(rt::SceneView sc, rt::FrameParams fp, StripeMap sm,
                                                                     int local_rows, FrameBuffers fb, BatchParams bp,
                                                                     unsigned int *work_counter, SchedParams sched)
 {
@@ -541,10 +545,10 @@ int launch_tiles(rt_context *c, const rt::FrameParams &fp, bool sum)
     return RT_OK;
 }
 
-template <int STACK, bool COUNT, bool FUSED, int PARK>
+template <int STACK, bool COUNT, bool FUSED, int PARK, int MINW>
 int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchParams &bp, unsigned int *counter)
 {
-    auto kernel = render_persistent_kernel<STACK, COUNT, FUSED, PARK>;
+    auto kernel = render_persistent_kernel<STACK, COUNT, FUSED, PARK, MINW>;
     int per_cu = c->tune_blocks_per_cu;
     if (per_cu <= 0) {
         RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
@@ -569,12 +573,14 @@ int launch_persistent_d(rt_context *c, const rt::FrameParams &fp, const BatchPar
     const rt::BuiltScene &hs = c->host_scene;
     bool small = c->tune_lds_state >= 1 && hs.n_tris <= 4096 && hs.nodes.size() / 4 < 32768 && hs.nodes4.size() / 8 < 32768 && depth <= 32;
     if (small) {
-        if (depth <= RT_PARK2_STACK && c->tune_lds_state >= 2) return launch_persistent_t<RT_PARK2_STACK, COUNT, FUSED, RT_PARK2_SLOTS>(c, fp, bp, counter);
-        return launch_persistent_t<32, COUNT, FUSED, 12>(c, fp, bp, counter);
+        if (depth <= RT_PARK2_STACK && c->tune_lds_state >= 2) return launch_persistent_t<RT_PARK2_STACK, COUNT, FUSED, RT_PARK2_SLOTS, RT_PARK2_MINW>(c, fp, bp, counter);
+        return launch_persistent_t<32, COUNT, FUSED, 12, RT_MINW>(c, fp, bp, counter);
     }
-    if (depth <= 16) return launch_persistent_t<16, COUNT, FUSED, 0>(c, fp, bp, counter);
-    if (depth <= 32) return launch_persistent_t<32, COUNT, FUSED, 0>(c, fp, bp, counter);
-    if (depth <= 64) return launch_persistent_t<64, COUNT, FUSED, 0>(c, fp, bp, counter);
+    // 32-bit entries: 31 of them keep a block under 32 KB of LDS (five blocks per CU), 47 allow three
+    if (depth <= 16) return launch_persistent_t<16, COUNT, FUSED, 0, RT_MINW>(c, fp, bp, counter);
+    if (depth <= 31) return launch_persistent_t<31, COUNT, FUSED, 0, RT_MINW>(c, fp, bp, counter);
+    if (depth <= 47) return launch_persistent_t<47, COUNT, FUSED, 0, RT_MINW>(c, fp, bp, counter);
+    if (depth <= 64) return launch_persistent_t<64, COUNT, FUSED, 0, RT_MINW>(c, fp, bp, counter);
     return fail(RT_ERR_UNSUPPORTED, "acceleration structure too deep for the traversal stack");
 }
 

@@ -3,9 +3,14 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from raytracer_amd import capi, scene as S
 from tests.synth import subdivided_suzanne_packed
-levels = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+levels = int(sys.argv[1]) if len(sys.argv) > 1 else 5   # negative: height field of (-levels)^2 quads instead
 W, H, spp, frames = 1920, 1080, 16, int(sys.argv[2]) if len(sys.argv) > 2 else 4
-cam, sp, tr = subdivided_suzanne_packed(levels)
+if levels < 0:
+    from tests.synth import heightfield_scene
+    hf = heightfield_scene(-levels)
+    cam, sp, tr = hf.camera, S.pack_spheres(hf.spheres), S.pack_triangles(hf.triangles)
+else:
+    cam, sp, tr = subdivided_suzanne_packed(levels)
 ctx = capi.Context(W, H)
 ctx.set_max_bounces(8)
 t = time.time(); ctx.set_scene(sp, tr); ctx.sync(); t_scene = time.time() - t
