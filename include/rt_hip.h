@@ -53,9 +53,11 @@ typedef enum rt_tuning {
     RT_TUNE_BLOCKS_PER_CU = 2, /* resident 256-thread blocks per CU; 0 = occupancy query                        */
     RT_TUNE_BATCH_FRAMES = 3,  /* frames traced per launch by rt_render_frames; 0 = automatic (default)        */
     RT_TUNE_SHADOW_DONE_LANES = 4, /* finish shadow rays once this many lanes of a wave wait for it (1..64)     */
-    RT_TUNE_REFILL_LANES = 5,  /* fetch new pixels once this many lanes of a wave are idle (1..64)              */
+    RT_TUNE_REFILL_LANES = 5,  /* fetch new pixels once this many lanes of a wave are idle (1..64); 0 = by spp   */
     RT_TUNE_MAX_LEAF = 6,      /* triangles per BVH leaf, 1..8; takes effect at the next rt_set_scene           */
     RT_TUNE_TRI_COST_X10 = 7,  /* SAH cost of a triangle test relative to a node visit, in tenths; next rt_set_scene */
+    RT_TUNE_OVERLAP_FRAMES = 9, /* single-frame renders: 1 = trace on alternating side streams so that consecutive
+                                  frames overlap (default), 0 = trace and accumulate in one kernel on the context's stream */
     RT_TUNE_LDS_STATE = 8      /* scenes of <= 4096 triangles: 2 = per-pixel and shadow-ray lane state in LDS (default),
                                   1 = shadow-ray state only, 0 = all lane state in registers (as for larger scenes)  */
 } rt_tuning;
@@ -118,7 +120,10 @@ int rt_set_tuning(rt_context *ctx, int key, int value);
  * Render one frame with the current uniforms: the compute pass
  * (dispatchWorkgroups, src/webgpu-renderer.ts:253-260) followed by the
  * accumulator pass (src/accumulator.ts:63-78), as one submission
- * (src/webgpu-renderer.ts:267).  Asynchronous.
+ * (src/webgpu-renderer.ts:267).  Asynchronous, like the reference's
+ * fire-and-forget submit: frames submitted back to back are traced
+ * concurrently (the next frame fills the GPU while the last pixels of the
+ * previous one finish) and accumulated in frame order.
  */
 int rt_render_frame(rt_context *ctx);
 
@@ -134,8 +139,10 @@ int rt_render_frames(rt_context *ctx, uint32_t first_frame_index, uint32_t n_fra
 /* Wait for all submitted work of the context. */
 int rt_sync(rt_context *ctx);
 
-/* Milliseconds the GPU spent in the most recent rt_render_frame /
- * rt_render_frames call (HIP events on the context's stream); waits for it. */
+/* Milliseconds between the start and the end on the GPU of the most recent
+ * rt_render_frame / rt_render_frames call (HIP events); waits for it.  Single
+ * frames submitted back to back overlap on the GPU, so their times do not add
+ * up to the elapsed time. */
 int rt_last_render_ms(rt_context *ctx, float *ms);
 
 /*

@@ -207,6 +207,9 @@ struct BatchParams {
     uint2 *colors;        // [n_frames][local_rows * width] rgba16float bit patterns (unused when FUSED)
     uint32_t stride;      // frameIndex step between batch frames (1, or the rank count when frames are dealt to ranks)
     bool sum;             // accumulator planes collect plain sums of the frame colours
+    int32_t *ids;         // [height * width] where the last batch frame's primary-hit ids go: the context's id
+                          // plane, or a staging plane that the accumulate kernel copies from (overlapped frames)
+    bool copy_ids;        // accumulate kernel: copy `ids` into the context's id plane
 };
 
 // PARK > 0: links fit 16 bits (<= 4096 triangles), so the stack uses 16-bit entries and the
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(kBlock, MINW) void render_persistent_kernel(rt::Sce
                 packed.x = (uint32_t)rt::f32_to_f16_bits(color.x) | ((uint32_t)rt::f32_to_f16_bits(color.y) << 16);
                 packed.y = (uint32_t)rt::f32_to_f16_bits(color.z) | (0x3c00u << 16);
                 bp.colors[(size_t)frame_k * ((size_t)local_rows * fp.width) + lp] = packed;
-                if (frame_k + 1u == bp.n_frames) fb.ids[(size_t)py * fp.width + px] = rt::lane_primary_id(park);
+                if (frame_k + 1u == bp.n_frames) bp.ids[(size_t)py * fp.width + px] = rt::lane_primary_id(park);
             }
             L.mode = rt::kLaneNeedUnit;
         }
@@ -413,6 +416,7 @@ __global__ void accumulate_batch_kernel(FrameBuffers fb, BatchParams bp, int wid
     fb.accum[plane + p] = g;
     fb.accum[2 * plane + p] = b;
     reinterpret_cast<uint2 *>(fb.frame_f16)[p] = packed;
+    if (bp.copy_ids) fb.ids[p] = bp.ids[p];
 }
 
 // planes := saturate(planes / divisor): closes a frame-split render (accumulator.wgsl:57-60 for
@@ -504,7 +508,18 @@ struct rt_context {
     uint32_t work_used = 0;
     uint2 *d_batch = nullptr;       // frame colours of a batch
     size_t batch_capacity = 0;      // in frames
-    int tune_shade_num = 2, tune_leaf_lanes = 12, tune_blocks_per_cu = 0, tune_batch = 0, tune_sdone_lanes = 2, tune_refill_lanes = 4, tune_max_leaf = 4, tune_tri_cost_x10 = 12, tune_lds_state = RT_LDS_PARK;
+    // Single-frame launches (rt_render_frame) alternate between two side streams so that the next
+    // frame's trace fills the CUs the previous one leaves idle while its last pixels finish; each
+    // has a staging slot for the frame colours and ids, and the accumulate step stays on `stream`,
+    // in frame order.
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t trace_done[2] = {nullptr, nullptr}, slot_free[2] = {nullptr, nullptr};
+    uint2 *d_slot[2] = {nullptr, nullptr};
+    int32_t *d_slot_ids[2] = {nullptr, nullptr};
+    bool slot_used[2] = {false, false};
+    int next_slot = 0;
+    int tune_overlap = 1;
+    int tune_shade_num = 2, tune_leaf_lanes = 12, tune_blocks_per_cu = 0, tune_batch = 0, tune_sdone_lanes = 2, tune_refill_lanes = 0, tune_max_leaf = 4, tune_tri_cost_x10 = 12, tune_lds_state = RT_LDS_PARK;
 
     void free_scene()
     {
@@ -546,7 +561,7 @@ int launch_tiles(rt_context *c, const rt::FrameParams &fp, bool sum)
 }
 
 template <int STACK, bool COUNT, bool FUSED, int PARK, int MINW>
-int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchParams &bp, unsigned int *counter)
+int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchParams &bp, unsigned int *counter, hipStream_t stream)
 {
     auto kernel = render_persistent_kernel<STACK, COUNT, FUSED, PARK, MINW>;
     int per_cu = c->tune_blocks_per_cu;
@@ -557,15 +572,19 @@ int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchPar
     uint64_t tiles = (uint64_t)((c->width + 7) / 8) * (uint64_t)((c->local_rows + 7) / 8) * bp.n_frames;
     uint64_t blocks = std::min<uint64_t>((uint64_t)c->n_cus * per_cu, (tiles + 3) / 4);
     if (blocks == 0) return RT_OK;
-    SchedParams sched{c->tune_shade_num, c->tune_leaf_lanes, c->tune_sdone_lanes, c->tune_refill_lanes};
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, c->view, fp, c->sm, c->local_rows, c->fb,
+    // Starting a pixel (seed, jitter, camera ray) is long code: with few samples per pixel it runs
+    // often, so more idle lanes are collected before a refill (measured optimum per spp).
+    int refill = c->tune_refill_lanes;
+    if (refill <= 0) refill = fp.spp <= 1u ? 32 : fp.spp <= 2u ? 24 : fp.spp <= 4u ? 16 : fp.spp <= 8u ? 8 : 4;
+    SchedParams sched{c->tune_shade_num, c->tune_leaf_lanes, c->tune_sdone_lanes, refill};
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, c->view, fp, c->sm, c->local_rows, c->fb,
                        bp, counter, sched);
     RT_HIP_CHECK(hipGetLastError());
     return RT_OK;
 }
 
 template <bool COUNT, bool FUSED>
-int launch_persistent_d(rt_context *c, const rt::FrameParams &fp, const BatchParams &bp, unsigned int *counter)
+int launch_persistent_d(rt_context *c, const rt::FrameParams &fp, const BatchParams &bp, unsigned int *counter, hipStream_t stream)
 {
     // entries the traversal stack must hold (one spare for the binary tree's branch-free variant)
     uint32_t depth = rt::kWideBvh ? c->host_scene.max_stack4 : c->host_scene.max_depth + 1;
@@ -573,15 +592,30 @@ int launch_persistent_d(rt_context *c, const rt::FrameParams &fp, const BatchPar
     const rt::BuiltScene &hs = c->host_scene;
     bool small = c->tune_lds_state >= 1 && hs.n_tris <= 4096 && hs.nodes.size() / 4 < 32768 && hs.nodes4.size() / 8 < 32768 && depth <= 32;
     if (small) {
-        if (depth <= RT_PARK2_STACK && c->tune_lds_state >= 2) return launch_persistent_t<RT_PARK2_STACK, COUNT, FUSED, RT_PARK2_SLOTS, RT_PARK2_MINW>(c, fp, bp, counter);
-        return launch_persistent_t<32, COUNT, FUSED, 12, RT_MINW>(c, fp, bp, counter);
+        if (depth <= RT_PARK2_STACK && c->tune_lds_state >= 2) return launch_persistent_t<RT_PARK2_STACK, COUNT, FUSED, RT_PARK2_SLOTS, RT_PARK2_MINW>(c, fp, bp, counter, stream);
+        return launch_persistent_t<32, COUNT, FUSED, 12, RT_MINW>(c, fp, bp, counter, stream);
     }
     // 32-bit entries: 31 of them keep a block under 32 KB of LDS (five blocks per CU), 47 allow three
-    if (depth <= 16) return launch_persistent_t<16, COUNT, FUSED, 0, RT_MINW>(c, fp, bp, counter);
-    if (depth <= 31) return launch_persistent_t<31, COUNT, FUSED, 0, RT_MINW>(c, fp, bp, counter);
-    if (depth <= 47) return launch_persistent_t<47, COUNT, FUSED, 0, RT_MINW>(c, fp, bp, counter);
-    if (depth <= 64) return launch_persistent_t<64, COUNT, FUSED, 0, RT_MINW>(c, fp, bp, counter);
+    if (depth <= 16) return launch_persistent_t<16, COUNT, FUSED, 0, RT_MINW>(c, fp, bp, counter, stream);
+    if (depth <= 31) return launch_persistent_t<31, COUNT, FUSED, 0, RT_MINW>(c, fp, bp, counter, stream);
+    if (depth <= 47) return launch_persistent_t<47, COUNT, FUSED, 0, RT_MINW>(c, fp, bp, counter, stream);
+    if (depth <= 64) return launch_persistent_t<64, COUNT, FUSED, 0, RT_MINW>(c, fp, bp, counter, stream);
     return fail(RT_ERR_UNSUPPORTED, "acceleration structure too deep for the traversal stack");
+}
+
+// Side streams, events and staging slots of the overlapped single-frame path, made on first use.
+int ensure_slots(rt_context *c)
+{
+    if (c->aux[0]) return RT_OK;
+    size_t local_px = (size_t)c->local_rows * c->width, px = (size_t)c->width * c->height;
+    for (int k = 0; k < 2; k++) {
+        RT_HIP_CHECK(hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
+        RT_HIP_CHECK(hipEventCreateWithFlags(&c->trace_done[k], hipEventDisableTiming));
+        RT_HIP_CHECK(hipEventCreateWithFlags(&c->slot_free[k], hipEventDisableTiming));
+        RT_HIP_CHECK(hipMalloc((void **)&c->d_slot[k], std::max<size_t>(local_px, 1) * sizeof(uint2)));
+        RT_HIP_CHECK(hipMalloc((void **)&c->d_slot_ids[k], px * sizeof(int32_t)));
+    }
+    return RT_OK;
 }
 
 // Frames first, first + stride, ... (n of them) through the persistent kernel, in batches.
@@ -602,18 +636,43 @@ int launch_persistent(rt_context *c, uint32_t first, uint32_t n, uint32_t stride
     uint32_t done = 0;
     while (done < n) {
         uint32_t b = std::min(max_batch, n - done);
-        if (c->work_used == 0) RT_HIP_CHECK(hipMemsetAsync(c->d_work, 0, kWorkCounters * sizeof(unsigned int), c->stream));
         unsigned int *counter = c->d_work + c->work_used;
         c->work_used = (c->work_used + 1) % kWorkCounters;
         c->uniforms[12] = (float)(first + done * stride);
         rt::FrameParams fp;
         std::string err;
         if (!rt::make_frame_params(c->uniforms, c->max_bounces, fp, err)) return fail(RT_ERR_INVALID, err);
-        BatchParams bp{first + done * stride, b, nullptr, stride, sum};
+        BatchParams bp{first + done * stride, b, nullptr, stride, sum, c->fb.ids, false};
+        dim3 acc_grid((unsigned)((local_px + 255) / 256));
         int rc;
-        if (b == 1) {
-            rc = c->counting ? launch_persistent_d<true, true>(c, fp, bp, counter) : launch_persistent_d<false, true>(c, fp, bp, counter);
+        if (b == 1 && !c->tune_overlap) {
+            // one frame, accumulated by the trace kernel itself
+            RT_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned int), c->stream));
+            rc = c->counting ? launch_persistent_d<true, true>(c, fp, bp, counter, c->stream)
+                             : launch_persistent_d<false, true>(c, fp, bp, counter, c->stream);
             if (rc) return rc;
+        } else if (b == 1) {
+            // one frame, traced on a side stream into a staging slot, accumulated on the main stream
+            if ((rc = ensure_slots(c))) return rc;
+            int k = c->next_slot;
+            c->next_slot ^= 1;
+            if (c->slot_used[k]) RT_HIP_CHECK(hipStreamWaitEvent(c->aux[k], c->slot_free[k], 0));
+            bp.colors = c->d_slot[k];
+            bp.ids = c->d_slot_ids[k];
+            bp.copy_ids = true;
+            // rt_last_render_ms spans from the first trace to the last accumulate: restart its first event here
+            if (done == 0) RT_HIP_CHECK(hipEventRecord(c->ev_start, c->aux[k]));
+            RT_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned int), c->aux[k]));
+            rc = c->counting ? launch_persistent_d<true, false>(c, fp, bp, counter, c->aux[k])
+                             : launch_persistent_d<false, false>(c, fp, bp, counter, c->aux[k]);
+            if (rc) return rc;
+            RT_HIP_CHECK(hipEventRecord(c->trace_done[k], c->aux[k]));
+            RT_HIP_CHECK(hipStreamWaitEvent(c->stream, c->trace_done[k], 0));
+            hipLaunchKernelGGL(accumulate_batch_kernel, acc_grid, dim3(256), 0, c->stream, c->fb, bp, c->width, c->height,
+                               c->local_rows, c->sm);
+            RT_HIP_CHECK(hipGetLastError());
+            RT_HIP_CHECK(hipEventRecord(c->slot_free[k], c->stream));
+            c->slot_used[k] = true;
         } else {
             if (c->batch_capacity < b) {
                 if (c->d_batch) { RT_HIP_CHECK(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_batch); c->d_batch = nullptr; c->batch_capacity = 0; }
@@ -621,10 +680,12 @@ int launch_persistent(rt_context *c, uint32_t first, uint32_t n, uint32_t stride
                 c->batch_capacity = max_batch;
             }
             bp.colors = c->d_batch;
-            rc = c->counting ? launch_persistent_d<true, false>(c, fp, bp, counter) : launch_persistent_d<false, false>(c, fp, bp, counter);
+            RT_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned int), c->stream));
+            rc = c->counting ? launch_persistent_d<true, false>(c, fp, bp, counter, c->stream)
+                             : launch_persistent_d<false, false>(c, fp, bp, counter, c->stream);
             if (rc) return rc;
-            hipLaunchKernelGGL(accumulate_batch_kernel, dim3((unsigned)((local_px + 255) / 256)), dim3(256), 0, c->stream, c->fb, bp,
-                               c->width, c->height, c->local_rows, c->sm);
+            hipLaunchKernelGGL(accumulate_batch_kernel, acc_grid, dim3(256), 0, c->stream, c->fb, bp, c->width, c->height,
+                               c->local_rows, c->sm);
             RT_HIP_CHECK(hipGetLastError());
         }
         done += b;
@@ -703,6 +764,12 @@ void rt_destroy(rt_context *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->free_scene();
+    for (int k = 0; k < 2; k++) {
+        if (c->aux[k]) { (void)hipStreamSynchronize(c->aux[k]); (void)hipStreamDestroy(c->aux[k]); }
+        if (c->trace_done[k]) (void)hipEventDestroy(c->trace_done[k]);
+        if (c->slot_free[k]) (void)hipEventDestroy(c->slot_free[k]);
+        (void)hipFree(c->d_slot[k]); (void)hipFree(c->d_slot_ids[k]);
+    }
     (void)hipFree(c->d_work); (void)hipFree(c->d_batch);
     (void)hipFree(c->fb.accum); (void)hipFree(c->fb.frame_f16); (void)hipFree(c->fb.ids); (void)hipFree(c->fb.counters);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -782,7 +849,8 @@ int rt_set_tuning(rt_context *c, int key, int value)
     case RT_TUNE_BATCH_FRAMES: if (value < 0 || value > 4096) return fail(RT_ERR_INVALID, "batch_frames out of range"); c->tune_batch = value; break;
     case RT_TUNE_MAX_LEAF: if (value < 1 || value > 8) return fail(RT_ERR_INVALID, "max_leaf out of range"); c->tune_max_leaf = value; break;
     case RT_TUNE_TRI_COST_X10: if (value < 1 || value > 1000) return fail(RT_ERR_INVALID, "tri_cost out of range"); c->tune_tri_cost_x10 = value; break;
-    case RT_TUNE_REFILL_LANES: if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "refill_lanes out of range"); c->tune_refill_lanes = value; break;
+    case RT_TUNE_REFILL_LANES: if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "refill_lanes out of range"); c->tune_refill_lanes = value; break;
+    case RT_TUNE_OVERLAP_FRAMES: if (value < 0 || value > 1) return fail(RT_ERR_INVALID, "overlap_frames out of range"); c->tune_overlap = value; break;
     case RT_TUNE_LDS_STATE: if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "lds_state out of range"); c->tune_lds_state = value; break;
     case RT_TUNE_SHADOW_DONE_LANES: if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "shadow_done_lanes out of range"); c->tune_sdone_lanes = value; break;
     default: return fail(RT_ERR_INVALID, "unknown tuning key");

@@ -1,4 +1,4 @@
-import sys, time
+import os, sys, time
 sys.path.insert(0, '/root/repo')
 import numpy as np
 from raytracer_amd import capi, scene as S
@@ -7,13 +7,18 @@ mode = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 sc = S.load_scene(S.scene_path(name))
 ctx = capi.Context(W, H)
 ctx.set_mode(mode)
-import os
-for k, name_ in enumerate(['SHADE', 'LEAF', 'BPC', 'BATCH', 'SDONE', 'REFILL']):
+for k, name_ in enumerate(['SHADE', 'LEAF', 'BPC', 'BATCH', 'SDONE', 'REFILL', 'MAXLEAF', 'TRICOST', 'LDS', 'OVERLAP']):
     if 'RT_' + name_ in os.environ: ctx.set_tuning(k, int(os.environ['RT_' + name_]))
 ctx.set_scene(S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles))
 ctx.set_uniforms(S.pack_uniforms(sc.camera, 1, W, H, spp))
 ctx.render_frames(1, 1); ctx.sync()
 c0 = ctx.read_counters()[13]
-t = time.time(); ctx.render_frames(2, frames); ctx.sync(); dt = time.time() - t
+t = time.time()
+if os.environ.get('QB_SINGLE'):
+    for f in range(frames):
+        ctx.set_uniforms(S.pack_uniforms(sc.camera, 2 + f, W, H, spp)); ctx.render_frame()
+else:
+    ctx.render_frames(2, frames)
+ctx.sync(); dt = time.time() - t
 c1 = ctx.read_counters()[13]
 print(name, W, H, frames, spp, 'mode', mode, {k: v for k, v in os.environ.items() if k.startswith('RT_')}, 'ms/frame %.3f' % (dt * 1e3 / frames), 'gpu ms %.3f' % ctx.last_render_ms(), 'Mrays/s %.1f' % ((c1 - c0) / dt / 1e6), ctx.scene_stats())

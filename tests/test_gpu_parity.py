@@ -290,3 +290,34 @@ def test_invalid_arguments_are_rejected(scenes):
         capi.Context(0, 9)
     with pytest.raises(capi.RtError):
         capi.Context(16, 9, stripe_index=2, stripe_count=2)
+
+
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_back_to_back_single_frames(scenes, overlap):
+    """rt_render_frame called six times without waiting in between: with overlap the traces of consecutive
+    frames run concurrently on two side streams; the accumulate steps must still apply in frame order and
+    the ids and rgba16float frame must be those of the last frame.  overlap 0 = the fused single-kernel path."""
+    scene = scenes["suzanne"]
+    width, height, spp, frames = 160, 90, 3, 6
+    orc = O.OracleRenderer(scene, width, height)
+    orc.set_samples_per_pixel(spp)
+    orc.render_frames(frames)
+    ctx = capi.Context(width, height)
+    ctx.set_tuning(capi.RT_TUNE_OVERLAP_FRAMES, overlap)
+    ctx.set_scene(S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles))
+    for f in range(1, frames + 1):
+        ctx.set_uniforms(S.pack_uniforms(scene.camera, f, width, height, spp))
+        ctx.render_frame()
+    assert np.array_equal(ctx.read_primary_ids(), orc.ids)
+    assert _f16_equal(ctx.read_frame_f16(), orc.frame_f16)
+    assert np.array_equal(ctx.read_accum(), orc.accum_rgb())
+    assert int(ctx.read_counters()[0]) == int(orc.counters[0])
+    # a batch after single frames, then single frames again
+    orc.render_frames(5)
+    ctx.render_frames(frames + 1, 3)
+    for f in range(frames + 4, frames + 6):
+        ctx.set_uniforms(S.pack_uniforms(scene.camera, f, width, height, spp))
+        ctx.render_frame()
+    assert np.array_equal(ctx.read_primary_ids(), orc.ids)
+    assert np.array_equal(ctx.read_accum(), orc.accum_rgb())
+    ctx.close()
