@@ -56,22 +56,61 @@ __host__ __device__ inline int stripe_global_row(const StripeMap &m, int local)
 #ifndef RT_PARK2_SLOTS
 #define RT_PARK2_SLOTS 14
 #endif
+#ifndef RT_LARGE_STACK
+#define RT_LARGE_STACK 16 // large scenes (32-bit links): stack entries in LDS, the rest in global memory
+#endif
+#ifndef RT_LARGE_SLOTS
+#define RT_LARGE_SLOTS 12
+#endif
+#ifndef RT_LARGE_MINW
+#define RT_LARGE_MINW 5
+#endif
 #ifndef RT_PARK2_MINW
 #define RT_PARK2_MINW 6
 #endif
 
-template <int BLOCK, class Entry>
+template <int BLOCK, class Entry, int CAP = 1 << 30, bool SPILL = false>
 struct LdsStack {
     Entry *base;
     int sp;
+    // SPILL: entries CAP and above live in global memory, entry j of a lane at spill[(j - CAP) * spill_stride]
+    int32_t *spill;
+    uint32_t spill_stride;
     __device__ void reset() { sp = 0; }
-    __device__ void push(int32_t v) { base[sp * BLOCK] = (Entry)v; sp++; }
-    __device__ int32_t pop() { sp--; return (int32_t)base[sp * BLOCK]; }
+    __device__ void push(int32_t v)
+    {
+        if (!SPILL || sp < CAP) base[sp * BLOCK] = (Entry)v;
+        else spill[(size_t)(sp - CAP) * spill_stride] = v;
+        sp++;
+    }
+    __device__ int32_t pop()
+    {
+        sp--;
+        if (!SPILL || sp < CAP) return (int32_t)base[sp * BLOCK];
+        return spill[(size_t)(sp - CAP) * spill_stride];
+    }
     __device__ bool empty() const { return sp == 0; }
+    // peek / poke / advance serve the branch-free binary-tree step, which is not built with SPILL
     __device__ int32_t peek() const { return (int32_t)base[(sp > 0 ? sp - 1 : 0) * BLOCK]; }
     __device__ void poke(int32_t v) { base[sp * BLOCK] = (Entry)v; }
     __device__ void advance(int d) { sp += d; }
 };
+
+// How an instantiation of the persistent kernel keeps its per-lane state.
+//   STACK  traversal stack entries in LDS
+//   PARK   dwords of rarely touched lane state kept in LDS (0: all in registers; 12: what is set
+//          aside during shadow rays; more: per-pixel values too)
+//   MINW   waves per SIMD it is compiled for: 6 (80 VGPRs) needs STACK * entry size + PARK * 4 <=
+//          104 bytes per lane (26 KB per block, six blocks in a CU's 160 KB); 5 (96 VGPRs) needs it
+//          below 128 (at exactly 32 KB only four blocks fit)
+//   LINK16 links fit 16 bits (scenes of <= 4096 triangles): 2-byte stack entries
+//   SPILL  stack entries beyond STACK go to global memory (deep trees of large scenes)
+template <int STACK_, int PARK_, int MINW_, bool LINK16_, bool SPILL_>
+struct LaneCfg {
+    static constexpr int STACK = STACK_, PARK = PARK_, MINW = MINW_;
+    static constexpr bool LINK16 = LINK16_, SPILL = SPILL_;
+};
+constexpr int kSpillEntries = 64 - RT_LARGE_STACK; // trees whose traversal needs up to 64 entries
 
 // rt::RegPark's interface with the first NLDS slots in LDS (slot k of lane l at
 // base[k * BLOCK + l]) and the rest in registers.  Slot numbers are compile-time constants at
@@ -155,6 +194,8 @@ __global__ __launch_bounds__(kBlock) void render_tiles_kernel(rt::SceneView sc, 
             LdsStack<kBlock, int32_t> stack;
             stack.base = lds_stack + threadIdx.x;
             stack.sp = 0;
+            stack.spill = nullptr;
+            stack.spill_stride = 0;
             int32_t pid;
             rt::f3 color = rt::render_pixel<BRUTE>(sc, fp, px, py, stack, n_rays, pid, COUNT ? &cnt : nullptr);
             store_pixel(fp, fb, px, py, color, pid, sum);
@@ -212,24 +253,22 @@ struct BatchParams {
     bool copy_ids;        // accumulate kernel: copy `ids` into the context's id plane
 };
 
-// PARK > 0: links fit 16 bits (<= 4096 triangles), so the stack uses 16-bit entries and the
-// room saved in LDS holds the first PARK slots of the lanes' rarely touched state (12: what is
-// set aside during shadow rays; more: per-pixel values too).  PARK == 0: 32-bit entries, all
-// state in registers.  MINW = waves per SIMD the instantiation is compiled for: 6 (80 VGPRs)
-// needs STACK * sizeof(entry) + PARK * 4 <= 104 bytes per lane (26 KB per block, six blocks in
-// a CU's 160 KB), 5 (96 VGPRs) needs it below 128 (at exactly 32 KB only four blocks fit).
-template <int STACK, bool COUNT, bool FUSED, int PARK, int MINW>
-__global__ __launch_bounds__(kBlock, MINW) void render_persistent_kernel(rt::SceneView sc, rt::FrameParams fp, StripeMap sm,
+template <class CFG, bool COUNT, bool FUSED>
+__global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt::SceneView sc, rt::FrameParams fp, StripeMap sm,
                                                                     int local_rows, FrameBuffers fb, BatchParams bp,
-                                                                    unsigned int *work_counter, SchedParams sched)
+                                                                    unsigned int *work_counter, SchedParams sched,
+                                                                    int32_t *spill)
 {
-    using StackEntry = typename std::conditional<(PARK > 0), int16_t, int32_t>::type;
+    constexpr int STACK = CFG::STACK, PARK = CFG::PARK;
+    using StackEntry = typename std::conditional<CFG::LINK16, int16_t, int32_t>::type;
     __shared__ StackEntry lds_stack[STACK * kBlock];
     __shared__ float lds_park[PARK > 0 ? PARK * kBlock : 1];
     const int lane = threadIdx.x & 63;
-    LdsStack<kBlock, StackEntry> stack;
+    LdsStack<kBlock, StackEntry, STACK, CFG::SPILL> stack;
     stack.base = lds_stack + threadIdx.x;
     stack.sp = 0;
+    stack.spill = CFG::SPILL ? spill + ((size_t)blockIdx.x * kBlock + threadIdx.x) : nullptr;
+    stack.spill_stride = gridDim.x * kBlock;
     LdsPark<kBlock, PARK> park;
     park.base = lds_park + threadIdx.x;
 
@@ -517,6 +556,8 @@ struct rt_context {
     uint2 *d_slot[2] = {nullptr, nullptr};
     int32_t *d_slot_ids[2] = {nullptr, nullptr};
     bool slot_used[2] = {false, false};
+    int32_t *d_spill[3] = {nullptr, nullptr, nullptr}; // traversal stack overflow, per stream (main, side 0, side 1)
+    size_t spill_bytes[3] = {0, 0, 0};
     int next_slot = 0;
     int tune_overlap = 1;
     int tune_shade_num = 2, tune_leaf_lanes = 12, tune_blocks_per_cu = 0, tune_batch = 0, tune_sdone_lanes = 2, tune_refill_lanes = 0, tune_max_leaf = 4, tune_tri_cost_x10 = 12, tune_lds_state = RT_LDS_PARK;
@@ -560,10 +601,10 @@ int launch_tiles(rt_context *c, const rt::FrameParams &fp, bool sum)
     return RT_OK;
 }
 
-template <int STACK, bool COUNT, bool FUSED, int PARK, int MINW>
+template <class CFG, bool COUNT, bool FUSED>
 int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchParams &bp, unsigned int *counter, hipStream_t stream)
 {
-    auto kernel = render_persistent_kernel<STACK, COUNT, FUSED, PARK, MINW>;
+    auto kernel = render_persistent_kernel<CFG, COUNT, FUSED>;
     int per_cu = c->tune_blocks_per_cu;
     if (per_cu <= 0) {
         RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
@@ -572,35 +613,54 @@ int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchPar
     uint64_t tiles = (uint64_t)((c->width + 7) / 8) * (uint64_t)((c->local_rows + 7) / 8) * bp.n_frames;
     uint64_t blocks = std::min<uint64_t>((uint64_t)c->n_cus * per_cu, (tiles + 3) / 4);
     if (blocks == 0) return RT_OK;
+    if (CFG::SPILL) {
+        // one column of kSpillEntries per lane of the grid; launches that share it are serialised by their
+        // streams only within a stream, so every stream (main, two side streams) has its own buffer
+        int which = stream == c->stream ? 0 : (stream == c->aux[0] ? 1 : 2);
+        size_t need = (size_t)blocks * kBlock * kSpillEntries * sizeof(int32_t);
+        if (c->spill_bytes[which] < need) {
+            RT_HIP_CHECK(hipStreamSynchronize(stream));
+            (void)hipFree(c->d_spill[which]);
+            c->d_spill[which] = nullptr;
+            c->spill_bytes[which] = 0;
+            RT_HIP_CHECK(hipMalloc((void **)&c->d_spill[which], need));
+            c->spill_bytes[which] = need;
+        }
+    }
+    int32_t *spill = CFG::SPILL ? c->d_spill[stream == c->stream ? 0 : (stream == c->aux[0] ? 1 : 2)] : nullptr;
     // Starting a pixel (seed, jitter, camera ray) is long code: with few samples per pixel it runs
     // often, so more idle lanes are collected before a refill (measured optimum per spp).
     int refill = c->tune_refill_lanes;
     if (refill <= 0) refill = fp.spp <= 1u ? 32 : fp.spp <= 2u ? 24 : fp.spp <= 4u ? 16 : fp.spp <= 8u ? 8 : 4;
     SchedParams sched{c->tune_shade_num, c->tune_leaf_lanes, c->tune_sdone_lanes, refill};
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, c->view, fp, c->sm, c->local_rows, c->fb,
-                       bp, counter, sched);
+                       bp, counter, sched, spill);
     RT_HIP_CHECK(hipGetLastError());
     return RT_OK;
 }
+
+using CfgSmall = LaneCfg<RT_PARK2_STACK, RT_PARK2_SLOTS, RT_PARK2_MINW, true, false>;
+using CfgSmallDeep = LaneCfg<32, 12, RT_MINW, true, false>;
+using CfgLarge = LaneCfg<RT_LARGE_STACK, RT_LARGE_SLOTS, RT_LARGE_MINW, false, false>;
+using CfgLargeDeep = LaneCfg<RT_LARGE_STACK, RT_LARGE_SLOTS, RT_LARGE_MINW, false, true>;
+using CfgRegisters = LaneCfg<64, 0, RT_MINW, false, false>;
 
 template <bool COUNT, bool FUSED>
 int launch_persistent_d(rt_context *c, const rt::FrameParams &fp, const BatchParams &bp, unsigned int *counter, hipStream_t stream)
 {
     // entries the traversal stack must hold (one spare for the binary tree's branch-free variant)
     uint32_t depth = rt::kWideBvh ? c->host_scene.max_stack4 : c->host_scene.max_depth + 1;
+    if (depth > 64) return fail(RT_ERR_UNSUPPORTED, "acceleration structure too deep for the traversal stack");
+    if (c->tune_lds_state == 0 || !rt::kWideBvh) return launch_persistent_t<CfgRegisters, COUNT, FUSED>(c, fp, bp, counter, stream);
     // 16-bit links: node indices below 32768 and leaf codes (first << 3 | count - 1) below 32768
     const rt::BuiltScene &hs = c->host_scene;
-    bool small = c->tune_lds_state >= 1 && hs.n_tris <= 4096 && hs.nodes.size() / 4 < 32768 && hs.nodes4.size() / 8 < 32768 && depth <= 32;
+    bool small = hs.n_tris <= 4096 && hs.nodes.size() / 4 < 32768 && hs.nodes4.size() / 8 < 32768 && depth <= 32;
     if (small) {
-        if (depth <= RT_PARK2_STACK && c->tune_lds_state >= 2) return launch_persistent_t<RT_PARK2_STACK, COUNT, FUSED, RT_PARK2_SLOTS, RT_PARK2_MINW>(c, fp, bp, counter, stream);
-        return launch_persistent_t<32, COUNT, FUSED, 12, RT_MINW>(c, fp, bp, counter, stream);
+        if (depth <= (uint32_t)CfgSmall::STACK && c->tune_lds_state >= 2) return launch_persistent_t<CfgSmall, COUNT, FUSED>(c, fp, bp, counter, stream);
+        return launch_persistent_t<CfgSmallDeep, COUNT, FUSED>(c, fp, bp, counter, stream);
     }
-    // 32-bit entries: 31 of them keep a block under 32 KB of LDS (five blocks per CU), 47 allow three
-    if (depth <= 16) return launch_persistent_t<16, COUNT, FUSED, 0, RT_MINW>(c, fp, bp, counter, stream);
-    if (depth <= 31) return launch_persistent_t<31, COUNT, FUSED, 0, RT_MINW>(c, fp, bp, counter, stream);
-    if (depth <= 47) return launch_persistent_t<47, COUNT, FUSED, 0, RT_MINW>(c, fp, bp, counter, stream);
-    if (depth <= 64) return launch_persistent_t<64, COUNT, FUSED, 0, RT_MINW>(c, fp, bp, counter, stream);
-    return fail(RT_ERR_UNSUPPORTED, "acceleration structure too deep for the traversal stack");
+    if (depth <= (uint32_t)CfgLarge::STACK) return launch_persistent_t<CfgLarge, COUNT, FUSED>(c, fp, bp, counter, stream);
+    return launch_persistent_t<CfgLargeDeep, COUNT, FUSED>(c, fp, bp, counter, stream);
 }
 
 // Side streams, events and staging slots of the overlapped single-frame path, made on first use.
@@ -770,6 +830,7 @@ void rt_destroy(rt_context *c)
         if (c->slot_free[k]) (void)hipEventDestroy(c->slot_free[k]);
         (void)hipFree(c->d_slot[k]); (void)hipFree(c->d_slot_ids[k]);
     }
+    for (int32_t *p : c->d_spill) (void)hipFree(p);
     (void)hipFree(c->d_work); (void)hipFree(c->d_batch);
     (void)hipFree(c->fb.accum); (void)hipFree(c->fb.frame_f16); (void)hipFree(c->fb.ids); (void)hipFree(c->fb.counters);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
