@@ -181,7 +181,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
     const uint32_t total_tiles = tiles_per_frame * n_frames;
     std::vector<uint16_t> batch((size_t)n_frames * W * H * 4);
     std::atomic<uint32_t> work{0};
-    std::atomic<uint64_t> rays{0}, traversed{0};
+    std::atomic<uint64_t> rays{0}, traversed{0}, high{0};
 
     auto wave = [&]() {
         rt::Lane L[64];
@@ -256,6 +256,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
             }
         }
         rays += n_rays.calls; traversed += n_rays.traversed;
+        for (auto &x : st) { uint64_t hv = (uint64_t)x.high, cur = high.load(); while (hv > cur && !high.compare_exchange_weak(cur, hv)) {} }
     };
     std::vector<std::thread> th;
     for (int i = 1; i < n_threads; i++) th.emplace_back(wave);
@@ -271,6 +272,6 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
             if (k + 1 == n_frames && frame_f16) std::memcpy(frame_f16 + 4 * p, src, 8);
         }
     }
-    if (counters) { counters[0] += rays; counters[13] += traversed; counters[14] = bs.max_stack4; counters[15] = bs.nodes4.size() / 8; }
+    if (counters) { counters[0] += rays; counters[13] += traversed; counters[14] = bs.max_stack4; counters[15] = bs.nodes4.size() / 8; counters[7] = high; }
     return 0;
 }

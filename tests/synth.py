@@ -101,3 +101,23 @@ def edge_scenes() -> dict:
     many.append(copy.deepcopy(many[3]))
     out["many_spheres"] = S.Scene(camera=boxes.camera, spheres=many, triangles=boxes.triangles)
     return out
+
+
+def card_deck_scene(n_cards: int) -> S.Scene:
+    """scene_suzanne's room and light with its model replaced by n_cards parallel quads stacked along the
+    view axis, all facing the camera: every box of the tree overlaps every central ray, so the first
+    descent of a camera ray leaves siblings on the traversal stack at every level (the deepest stacks a
+    tree of that size can produce), and the nearest card must still win."""
+    base = S.load_scene(S.scene_path("suzanne"))
+    tris = list(base.triangles[:14])
+    z_front, z_back = -0.6, -4.4
+    for k in range(n_cards):
+        z = z_front + (z_back - z_front) * k / max(n_cards - 1, 1)
+        shrink = 0.2 * k / max(n_cards - 1, 1)              # cards further back are slightly smaller
+        x0, x1, y0, y1 = -1.2 + shrink, 1.2 - shrink, 0.3 + shrink, 2.3 - shrink
+        mat = dict(color=[0.3 + 0.6 * ((k * 7) % 10) / 10.0, 0.5, 0.9 - 0.5 * ((k * 3) % 10) / 10.0], emissionColor=[0, 0, 0],
+                   emissionStrength=0, smoothness=0.0, specularProbability=0.0)
+        a, b, c, d = [x0, y0, z], [x1, y0, z], [x1, y1, z], [x0, y1, z]
+        tris.append(dict(v0=a, v1=b, v2=c, **mat))           # counter-clockwise seen from +z: faces the camera
+        tris.append(dict(v0=a, v1=c, v2=d, **mat))
+    return S.Scene(camera=base.camera, spheres=base.spheres, triangles=tris)

@@ -109,3 +109,19 @@ def test_late_frame_indices(scenes):
     har.render(2)
     assert np.array_equal(har.frame_f16, orc.frame_f16)
     assert np.array_equal(har.accum, orc.accum)
+
+
+def test_card_deck_needs_more_than_sixteen_stack_entries():
+    """The scene the GPU suite uses to reach the traversal stack's overflow area (entries beyond the
+    16 kept in LDS for large scenes): the emulated lanes must actually get that deep, and still match."""
+    from tests.synth import card_deck_scene
+
+    scene = card_deck_scene(3000)
+    orc = O.OracleRenderer(scene, 40, 23)
+    orc.set_samples_per_pixel(2)
+    orc.render_frames(1)
+    har = HarnessRenderer(scene, 40, 23)
+    har.render_frames_lanes(2, 1, 1)
+    assert np.array_equal(har.ids, orc.ids)
+    assert np.array_equal(har.accum, orc.accum)
+    assert int(har.counters[7]) > 16 and len(scene.triangles) > 4096

@@ -321,3 +321,14 @@ def test_back_to_back_single_frames(scenes, overlap):
     assert np.array_equal(ctx.read_primary_ids(), orc.ids)
     assert np.array_equal(ctx.read_accum(), orc.accum_rgb())
     ctx.close()
+
+
+def test_card_deck_uses_the_stack_overflow_area():
+    """6,014 triangles stacked so that camera rays leave more than 16 entries on the traversal stack
+    (tests/test_core_cpu.py checks that depth on the emulated lanes): entries beyond the 16 in LDS go
+    to global memory."""
+    from tests.synth import card_deck_scene
+
+    scene = card_deck_scene(3000)
+    run_pair(scene, 40, 23, 2, 2, capi.RT_MODE_BVH)
+    run_batched(scene, 64, 36, 3, 2, 3)
