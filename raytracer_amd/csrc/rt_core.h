@@ -213,28 +213,8 @@ RT_HD float triangle_t(f3 ro, f3 rd, f3 v0, f3 e01, f3 e02)
     return t;
 }
 
-// The same test with every early return folded into one predicate: all
-// operations are evaluated and the result is t, or -1 if any of the shader's
-// return conditions holds.  Same value as triangle_t for every input (a NaN
-// passes all comparisons in both and comes back as NaN).
-RT_HD float triangle_t_flat(f3 ro, f3 rd, f3 v0, f3 e01, f3 e02)
-{
-    f3 h = cross(rd, e02);
-    float a = dot(e01, h);
-    float f = 1.0f / a;
-    f3 s = sub(ro, v0);
-    float u = f * dot(s, h);
-    f3 q = cross(s, e01);
-    float v = f * dot(rd, q);
-    float t = f * dot(e02, q);
-    bool miss = (fabsf(a) < 0.001f) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t < 0.01f);
-    return miss ? -1.0f : t;
-}
-
 // ---------------------------------------------------------------------------
-// Traversal.  `Stack` provides reset(), push(int32_t), pop() -> int32_t, empty(),
-// and for the branch-free node visit peek() (top entry, any value when empty),
-// poke(v) (store above the top without moving it) and advance(+1/0/-1).
+// Traversal.  `Stack` provides reset(), push(int32_t), pop() -> int32_t, empty().
 // ---------------------------------------------------------------------------
 
 struct RayBox {

@@ -90,10 +90,6 @@ struct LdsStack {
         return spill[(size_t)(sp - CAP) * spill_stride];
     }
     __device__ bool empty() const { return sp == 0; }
-    // peek / poke / advance serve the branch-free binary-tree step, which is not built with SPILL
-    __device__ int32_t peek() const { return (int32_t)base[(sp > 0 ? sp - 1 : 0) * BLOCK]; }
-    __device__ void poke(int32_t v) { base[sp * BLOCK] = (Entry)v; }
-    __device__ void advance(int d) { sp += d; }
 };
 
 // How an instantiation of the persistent kernel keeps its per-lane state.
@@ -648,8 +644,8 @@ using CfgRegisters = LaneCfg<64, 0, RT_MINW, false, false>;
 template <bool COUNT, bool FUSED>
 int launch_persistent_d(rt_context *c, const rt::FrameParams &fp, const BatchParams &bp, unsigned int *counter, hipStream_t stream)
 {
-    // entries the traversal stack must hold (one spare for the binary tree's branch-free variant)
-    uint32_t depth = rt::kWideBvh ? c->host_scene.max_stack4 : c->host_scene.max_depth + 1;
+    // entries the traversal stack must hold
+    uint32_t depth = rt::kWideBvh ? c->host_scene.max_stack4 : c->host_scene.max_depth;
     if (depth > 64) return fail(RT_ERR_UNSUPPORTED, "acceleration structure too deep for the traversal stack");
     if (c->tune_lds_state == 0 || !rt::kWideBvh) return launch_persistent_t<CfgRegisters, COUNT, FUSED>(c, fp, bp, counter, stream);
     // 16-bit links: node indices below 32768 and leaf codes (first << 3 | count - 1) below 32768

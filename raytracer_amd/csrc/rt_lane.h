@@ -5,7 +5,7 @@
 // same sample, bounce or kind of ray:
 //
 //   lane_begin_pixel   seed + camera ray, first path                     (:293-336)
-//   lane_step_inner    one BVH node visit      } ray_all for the closest-hit
+//   lane_step_node     one BVH node visit      } ray_all for the closest-hit
 //   lane_step_triangle one triangle of a leaf  } and the shadow query   (:15-39)
 //   lane_shade_closest after a closest-hit ray: sky on a miss (:198-202); on a
 //                      hit the whole bounce at once -- light sample (:211-216)
@@ -29,15 +29,6 @@
 #ifndef RT_WIDE_BVH
 #define RT_WIDE_BVH 1 // the lane state machine traverses the 4-wide tree (0: the binary tree)
 #endif
-#ifndef RT_SPHERE_BOX
-#define RT_SPHERE_BOX 0 // 1: reject spheres by a padded bounding-box test first (measured 11% slower: register pressure)
-#endif
-#ifndef RT_FLAT_INNER
-#define RT_FLAT_INNER 0
-#endif
-#ifndef RT_FLAT_TRI
-#define RT_FLAT_TRI 0
-#endif
 
 namespace rt {
 
@@ -49,13 +40,6 @@ enum : int32_t {
     kLanePixelDone = 4,    // all samples done; colour waits to be stored
     kLaneDead = 5          // no work left
 };
-
-#ifndef RT_SIGN_ORDERED
-#define RT_SIGN_ORDERED 1 // 4-wide node step fetches near/far planes by ray direction sign
-#endif
-#ifndef RT_PACKED_SLAB
-#define RT_PACKED_SLAB 0  // packed FMAs in the 4-wide node step (measured slower than scalar FMAs)
-#endif
 
 constexpr int32_t kNoHit = 0x7fffffff;
 constexpr bool kWideBvh = RT_WIDE_BVH != 0;
@@ -151,10 +135,6 @@ RT_HD void lane_test_spheres(const SceneView &sc, Lane &L, TestCounts *cnt)
 {
     for (uint32_t i = 0; i < sc.n_spheres; i++) {
         f4 s0 = sc.spheres[4 * i];
-        // Conservative rejection: a ray that misses the sphere's bounding box, widened by far
-        // more than f32 rounding can move the discriminant, gets -1 from sphere_t anyway.
-        float pad = fabsf(s0.w) * 1.001f + 1e-3f, tn_box;
-        if (RT_SPHERE_BOX && !slab(L.rb, s0.x - pad, s0.y - pad, s0.z - pad, s0.x + pad, s0.y + pad, s0.z + pad, INFINITY, tn_box)) continue;
         float tn;
         float t = sphere_t(L.o, L.d, s0, tn);
         if (cnt) cnt->spheres++;
@@ -189,7 +169,8 @@ RT_HD void lane_launch_ray(const SceneView &sc, Lane &L, Stack &stack, bool anyh
     if (L.cur == kNoRoot) L.mode = anyhit ? kLaneShadowDone : kLaneShadeClosest;
 }
 
-#if !RT_FLAT_INNER
+// One visit of a node of the binary tree (used when RT_WIDE_BVH is 0): the nearer hit child is
+// visited next, the other goes on the stack.
 template <class Stack>
 RT_HD void lane_step_inner(const SceneView &sc, Lane &L, Stack &stack, TestCounts *cnt)
 {
@@ -208,47 +189,12 @@ RT_HD void lane_step_inner(const SceneView &sc, Lane &L, Stack &stack, TestCount
     else if (h1) L.cur = c1;
     else lane_pop(L, stack);
 }
-#else
-// One node visit, written without branches: the far child is stored above the
-// stack top whether or not it is needed (sp only moves when both children are
-// hit) and the stack top is read before it is known to be needed, so that the
-// LDS latency overlaps the node fetch.  `Stack` must have room for one entry
-// above the deepest push.
-template <class Stack>
-RT_HD void lane_step_inner(const SceneView &sc, Lane &L, Stack &stack, TestCounts *cnt)
-{
-    const f4 *n = sc.nodes + 4 * (size_t)L.cur;
-    int32_t top = stack.peek();
-    f4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-    float tn0, tn1;
-    bool h0 = slab(L.rb, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, L.tmax, tn0);
-    bool h1 = slab(L.rb, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, L.tmax, tn1);
-    if (cnt) cnt->boxes++;
-    int32_t c0 = (int32_t)f2u(q3.x), c1 = (int32_t)f2u(q3.y);
-    bool both = h0 & h1, none = !(h0 | h1);
-    bool first0 = h0 & !(h1 & (tn1 < tn0)); // child 0 next: only it is hit, or both and it is not farther
-    int32_t near = first0 ? c0 : c1, far = first0 ? c1 : c0;
-    stack.poke(far);
-    bool empty = stack.empty();
-    stack.advance(both ? 1 : ((none & !empty) ? -1 : 0));
-    L.cur = none ? (empty ? kNoRoot : top) : near;
-    if (none & empty) L.mode = lane_flag(L, kBitAnyhit) ? kLaneShadowDone : kLaneShadeClosest;
-}
 
-#endif
-
-// a[i] * m - s for the four children of a node at once (two packed FMAs on the device).
+// a[i] * m - s for the four children of a node.  (Packed v_pk_fma_f32 was measured slower here.)
 RT_HD void fma4(const f4 &a, float m, float s, float out[4])
 {
-#if defined(__HIP_DEVICE_COMPILE__) && RT_PACKED_SLAB
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    v2f mm = {m, m}, ss = {-s, -s};
-    v2f lo = __builtin_elementwise_fma((v2f){a.x, a.y}, mm, ss), hi = __builtin_elementwise_fma((v2f){a.z, a.w}, mm, ss);
-    out[0] = lo.x; out[1] = lo.y; out[2] = hi.x; out[3] = hi.y;
-#else
     out[0] = __builtin_fmaf(a.x, m, -s); out[1] = __builtin_fmaf(a.y, m, -s);
     out[2] = __builtin_fmaf(a.z, m, -s); out[3] = __builtin_fmaf(a.w, m, -s);
-#endif
 }
 
 // One visit of a 4-wide node: four slab tests, the nearest hit child is visited
@@ -261,7 +207,6 @@ RT_HD void fma4(const f4 &a, float m, float s, float out[4])
 template <class Stack>
 RT_HD void lane_step_inner4(const SceneView &sc, Lane &L, Stack &stack, TestCounts *cnt)
 {
-#if RT_SIGN_ORDERED
     const char *node = (const char *)sc.nodes4;
     uint32_t at = (uint32_t)L.cur << 7;
     // byte offset of the near plane vector: lo (0/16/32) for a non-negative direction, hi (48/64/80) otherwise
@@ -286,17 +231,6 @@ RT_HD void lane_step_inner4(const SceneView &sc, Lane &L, Stack &stack, TestCoun
     int32_t c0 = (int32_t)f2u(lk.x), c1 = (int32_t)f2u(lk.y), c2 = (int32_t)f2u(lk.z), c3 = (int32_t)f2u(lk.w);
     // children 0 and 1 always exist; an unused slot (link kNoRoot) is never a hit whatever its box says
     bool h0 = h[0], h1 = h[1], h2 = h[2] & (c2 != kNoRoot), h3 = h[3] & (c3 != kNoRoot);
-#else
-    const f4 *n = sc.nodes4 + 8 * (size_t)L.cur;
-    f4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], lk = n[6];
-    float t0, t1, t2, t3;
-    int32_t c0 = (int32_t)f2u(lk.x), c1 = (int32_t)f2u(lk.y), c2 = (int32_t)f2u(lk.z), c3 = (int32_t)f2u(lk.w);
-    // children 0 and 1 always exist; an unused slot (link kNoRoot) is never a hit whatever its box says
-    bool h0 = slab(L.rb, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, L.tmax, t0);
-    bool h1 = slab(L.rb, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, L.tmax, t1);
-    bool h2 = slab(L.rb, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, L.tmax, t2) & (c2 != kNoRoot);
-    bool h3 = slab(L.rb, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, L.tmax, t3) & (c3 != kNoRoot);
-#endif
     if (cnt) cnt->boxes += 2; // counted in box pairs
     // nearest hit child
     float tb = INFINITY;
@@ -330,11 +264,7 @@ RT_HD void lane_step_triangle(const SceneView &sc, Lane &L, Stack &stack, TestCo
     uint32_t first = code >> 3, left = code & 7u; // triangles after this one
     const f4 *tr = sc.tri_isect + kTriRecord * (size_t)first;
     f4 a = tr[0], b = tr[1], c = tr[2];
-#if RT_FLAT_TRI
-    float t = triangle_t_flat(L.o, L.d, xyz(a), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x));
-#else
     float t = triangle_t(L.o, L.d, xyz(a), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x));
-#endif
     if (cnt) cnt->tris++;
     bool stop = false;
     if (t > 0.0f) {

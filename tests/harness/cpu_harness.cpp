@@ -19,9 +19,6 @@ struct HostStack {
     int32_t pop() { return data[--sp]; }
     bool empty() const { return sp == 0; }
     void reset() { sp = 0; }
-    int32_t peek() const { return data[sp > 0 ? sp - 1 : 0]; }
-    void poke(int32_t v) { data[sp] = v; if (sp + 1 > high) high = sp + 1; }
-    void advance(int d) { sp += d; }
     int high = 0;
 };
 } // namespace
