@@ -226,10 +226,11 @@ __global__ __launch_bounds__(kBlock) void render_tiles_kernel(rt::SceneView sc, 
 //     (suspended lanes keep their traversal stack in LDS);
 //   - triangle tests and the hand-over after a finished shadow ray are postponed
 //     until enough lanes wait for them.
-// Units are (frame, pixel) pairs of a batch of frames, frame-major.  With one
-// frame the finished pixel is accumulated in place (FUSED); with several the
-// frame colours go to a batch buffer and accumulate_batch_kernel applies the
-// recurrence in frame order.
+// Units are (frame, pixel) pairs of a batch of frames, frame-major.  The frame
+// colours go to a batch buffer (or, for a single frame, a staging slot) and
+// accumulate_batch_kernel applies the recurrence in frame order; FUSED instead
+// accumulates a finished pixel in place (single frames with
+// RT_TUNE_OVERLAP_FRAMES 0).
 // ---------------------------------------------------------------------------
 struct SchedParams {
     int shade_num;    // shade when traversing lanes * 8 < active lanes * shade_num
