@@ -123,7 +123,9 @@ int rt_set_tuning(rt_context *ctx, int key, int value);
  * (src/webgpu-renderer.ts:267).  Asynchronous, like the reference's
  * fire-and-forget submit: frames submitted back to back are traced
  * concurrently (the next frame fills the GPU while the last pixels of the
- * previous one finish) and accumulated in frame order.
+ * previous one finish) and accumulated in frame order.  At most two frames are
+ * in flight: a third call waits on the host for the oldest to finish, so a
+ * loop that never calls rt_sync cannot run ahead of the GPU.
  */
 int rt_render_frame(rt_context *ctx);
 

@@ -713,7 +713,10 @@ int launch_persistent(rt_context *c, uint32_t first, uint32_t n, uint32_t stride
             if ((rc = ensure_slots(c))) return rc;
             int k = c->next_slot;
             c->next_slot ^= 1;
-            if (c->slot_used[k]) RT_HIP_CHECK(hipStreamWaitEvent(c->aux[k], c->slot_free[k], 0));
+            // The slot is free once the accumulate step of the frame before last has read it.  Waiting for
+            // that on the host is the back-pressure of a render loop that never syncs: at most two
+            // frames are in flight.
+            if (c->slot_used[k]) RT_HIP_CHECK(hipEventSynchronize(c->slot_free[k]));
             bp.colors = c->d_slot[k];
             bp.ids = c->d_slot_ids[k];
             bp.copy_ids = true;

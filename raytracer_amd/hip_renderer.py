@@ -132,9 +132,10 @@ class HipRenderer:
                 self._fps_frames = 0
                 self._fps_last = now
             if self._enabled:
-                self.render()
-                self.ctx.sync()
+                self.render()   # no fence, as in the reference; the native call keeps at most two frames in flight
             k += 1
+        if self.ctx is not None:
+            self.ctx.sync()
 
     def get_triangle_tests_since_last_check(self) -> int:
         """src/webgpu-renderer.ts:301-321 (u32, zeroed by the read)."""

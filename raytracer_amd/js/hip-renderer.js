@@ -40,7 +40,9 @@ class HipRenderer {
         this._loopTimer = null;
     }
 
-    // src/webgpu-renderer.ts:48-103.  options: { device, maxBounces, stripeRows, stripeIndex, stripeCount }
+    // src/webgpu-renderer.ts:48-103.  options: { device, maxBounces, stripeRows, stripeIndex, stripeCount,
+    // presentEvery }: presentEvery = k copies the image into canvas.pixels on every k-th frame only (default 1,
+    // every frame as the reference's canvas pass does; the copy reads the accumulator back and so waits for the GPU)
     static async Create(canvas, scenePath, options) {
         const renderer = new HipRenderer(canvas);
         const opt = options || {};
@@ -52,6 +54,7 @@ class HipRenderer {
                     opt.device || 0, renderer.resolution.width, renderer.resolution.height,
                     opt.stripeRows || 8, opt.stripeIndex || 0, opt.stripeCount || 1);
                 if (opt.maxBounces !== undefined) renderer.native.setMaxBounces(renderer.handle, opt.maxBounces);
+                renderer.presentEvery = Math.max(1, opt.presentEvery | 0);
             } catch (error) {
                 throw new RethrownError('Failed to create pipelines', error);
             }
@@ -102,7 +105,8 @@ class HipRenderer {
         this.frameIndex++;
         this.writeUniforms();
         this.native.renderFrame(this.handle);
-        this.accumulator.render(null, this.canvas.pixels);
+        const present = this.canvas.pixels && this.frameIndex % (this.presentEvery || 1) === 0;
+        this.accumulator.render(null, present ? this.canvas.pixels : null);
     }
 
     // n calls of render() as one native submission
@@ -119,10 +123,9 @@ class HipRenderer {
     startRenderLoop() {
         const loop = () => {
             this.fpsCounter.updateFPS();
-            if (this._enabled) {
-                this.render();
-                this.native.sync(this.handle);
-            }
+            // no fence, as in the reference (src/webgpu-renderer.ts:267): the native render call
+            // itself waits when two frames are already in flight
+            if (this._enabled) this.render();
             this._loopTimer = setImmediate(loop);
         };
         this._loopTimer = setImmediate(loop);

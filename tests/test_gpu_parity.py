@@ -332,3 +332,41 @@ def test_card_deck_uses_the_stack_overflow_area():
     scene = card_deck_scene(3000)
     run_pair(scene, 40, 23, 2, 2, capi.RT_MODE_BVH)
     run_batched(scene, 64, 36, 3, 2, 3)
+
+
+def test_python_renderer_mirror(scenes, tmp_path):
+    """raytracer_amd.hip_renderer.HipRenderer: the reference class's sequencing (frameIndex incremented
+    before the uniforms are written, spp clamp, reset keeps the planes, counter zeroed by the read,
+    None on failure) over the native context, with an unfenced render loop."""
+    from raytracer_amd.hip_renderer import HipRenderer
+
+    assert HipRenderer.create(32, 18, str(tmp_path / "missing.json")) is None
+    width, height = 80, 45
+    r = HipRenderer.create(width, height, S.scene_path("spheres"))
+    assert r is not None
+    r.set_samples_per_pixel(100)
+    assert r.samples_per_pixel == 16
+    r.set_samples_per_pixel(0)
+    assert r.samples_per_pixel == 1
+    r.set_samples_per_pixel(3)
+    r.start_render_loop(frames=5)
+    orc = O.OracleRenderer(scenes["spheres"], width, height)
+    orc.set_samples_per_pixel(3)
+    orc.render_frames(5)
+    assert r.frame_index == 5
+    assert np.array_equal(r.read_accum(), orc.accum_rgb())
+    assert np.array_equal(r.read_ids(), orc.ids)
+    assert r.get_triangle_tests_since_last_check() == (int(orc.counters[0]) * 14) % 2**32
+    assert r.get_triangle_tests_since_last_check() == 0
+    r.reset_accumulation()
+    orc.reset_accumulation()
+    r.set_enabled(False)
+    r.start_render_loop(frames=2)          # disabled: nothing is rendered
+    assert r.frame_index == 0
+    r.set_enabled(True)
+    r.render_frames(2)
+    r.render()
+    orc.render_frames(3)
+    assert np.array_equal(r.read_accum(), orc.accum_rgb())
+    r.close()
+    r.render()                               # no resources: silent no-op (src/webgpu-renderer.ts:238-246)

@@ -98,3 +98,36 @@ def test_js_renderer_matches_oracle(scenes, tmp_path, per_frame):
     assert ppm.startswith(header)
     img = np.frombuffer(ppm[len(header):], np.uint8).reshape(height, width, 3)
     assert np.array_equal(img, np.floor(orc.accum_rgb().astype(np.float64) * 255 + 0.5).astype(np.uint8))
+
+
+@pytest.mark.gpu
+def test_js_render_loop_runs_unfenced_and_in_order(scenes, tmp_path):
+    """startRenderLoop submits one frame per tick with no fence, as the reference's loop does; the native
+    call keeps two frames in flight.  Stopped after at least 7 frames, the accumulator must equal the
+    oracle's after exactly that many."""
+    width, height, spp = 96, 54, 2
+    script = """
+const fs = require('fs');
+const { HipRenderer } = require('%(js)s/hip-renderer');
+const canvas = { width: %(w)d, height: %(h)d, pixels: new Uint8Array(%(w)d * %(h)d * 4) };
+HipRenderer.Create(canvas, '%(scene)s', { presentEvery: 4 }).then((r) => {
+  r.setSamplesPerPixel(%(spp)d);
+  r.startRenderLoop();
+  const poll = () => {
+    if (r.frameIndex < 7) return setImmediate(poll);
+    r.stopRenderLoop();
+    r.sync();
+    fs.writeFileSync('%(out)s', Buffer.from(r.readAccum().buffer));
+    console.log(JSON.stringify({ frames: r.frameIndex, fps: r.getFPS() }));
+    r.destroy();
+  };
+  setImmediate(poll);
+});
+""" % dict(js=JS, w=width, h=height, spp=spp, scene=S.scene_path("boxes"), out=str(tmp_path / "loop.f32"))
+    info = json.loads(node(script).strip().splitlines()[-1])
+    assert info["frames"] >= 7
+    orc = O.OracleRenderer(scenes["boxes"], width, height)
+    orc.set_samples_per_pixel(spp)
+    orc.render_frames(info["frames"])
+    acc = np.fromfile(tmp_path / "loop.f32", np.float32).reshape(height, width, 3)
+    assert np.array_equal(acc, orc.accum_rgb())
