@@ -640,7 +640,7 @@ using CfgSmall = LaneCfg<RT_PARK2_STACK, RT_PARK2_SLOTS, RT_PARK2_MINW, true, fa
 using CfgSmallDeep = LaneCfg<32, 12, RT_MINW, true, false>;
 using CfgLarge = LaneCfg<RT_LARGE_STACK, RT_LARGE_SLOTS, RT_LARGE_MINW, false, false>;
 using CfgLargeDeep = LaneCfg<RT_LARGE_STACK, RT_LARGE_SLOTS, RT_LARGE_MINW, false, true>;
-using CfgRegisters = LaneCfg<64, 0, RT_MINW, false, false>;
+using CfgRegisters = LaneCfg<64, 0, 2, false, false>; // 64 KB of LDS per block: two blocks per CU
 
 template <bool COUNT, bool FUSED>
 int launch_persistent_d(rt_context *c, const rt::FrameParams &fp, const BatchParams &bp, unsigned int *counter, hipStream_t stream)
