@@ -108,6 +108,9 @@ def main():
     # RT_BENCH_FORCE_DIST=1 runs the collective path even with one rank (smoke test of the RCCL calls)
     use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
     if use_dist:
+        if world == 1:  # forced collective path outside torch.distributed.run
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+                os.environ.setdefault(k, v)
         if rehearse:
             dist.init_process_group("gloo")
         else:
