@@ -782,6 +782,9 @@ int rt_create(int device, int width, int height, int stripe_rows, int stripe_ind
     if (width < 1 || height < 1 || width > 65536 || height > 65536) return fail(RT_ERR_INVALID, "width/height out of range");
     if (stripe_count < 1 || stripe_index < 0 || stripe_index >= stripe_count || stripe_rows < 1)
         return fail(RT_ERR_INVALID, "bad stripe assignment");
+    // work units of a launch are numbered in 32 bits: one frame of the image, padded to 8x8 tiles, must fit
+    if ((uint64_t)((width + 7) / 8) * (uint64_t)((height + 7) / 8) * 64u >= (1ull << 31))
+        return fail(RT_ERR_UNSUPPORTED, "image larger than 2^31 pixels");
     int n_dev = 0;
     RT_HIP_CHECK(hipGetDeviceCount(&n_dev));
     if (device < 0 || device >= n_dev) return fail(RT_ERR_DEVICE, "no such HIP device");
@@ -852,6 +855,8 @@ int rt_set_scene(rt_context *c, const void *spheres, uint32_t n_spheres, const v
     opt.triangle_cost = 0.1f * (float)c->tune_tri_cost_x10;
     rt::build_scene(spheres, n_spheres, triangles, n_triangles, opt, c->host_scene);
     if (c->host_scene.max_depth >= 64) return fail(RT_ERR_UNSUPPORTED, "acceleration structure too deep");
+    // the 4-wide node step addresses nodes by a 32-bit byte offset
+    if (c->host_scene.nodes4.size() * sizeof(rt::f4) >= (1ull << 32)) return fail(RT_ERR_UNSUPPORTED, "too many nodes");
     const rt::BuiltScene &hs = c->host_scene;
     int rc;
     if ((rc = upload(hs.nodes, &c->d_nodes, c->stream)) || (rc = upload(hs.nodes4, &c->d_nodes4, c->stream)) || (rc = upload(hs.tri_isect, &c->d_tri_isect, c->stream)) ||

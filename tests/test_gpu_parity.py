@@ -290,6 +290,8 @@ def test_invalid_arguments_are_rejected(scenes):
         capi.Context(0, 9)
     with pytest.raises(capi.RtError):
         capi.Context(16, 9, stripe_index=2, stripe_count=2)
+    with pytest.raises(capi.RtError):
+        capi.Context(65536, 65536)              # more (frame, pixel) units than a launch can number
 
 
 @pytest.mark.parametrize("overlap", [0, 1])
