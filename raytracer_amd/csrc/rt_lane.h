@@ -293,8 +293,20 @@ RT_HD void lane_step_triangle(const SceneView &sc, Lane &L, Stack &stack, TestCo
 template <class Park>
 RT_HD void lane_end_path(const FrameParams &fp, Lane &L, Park &park, RayCounts &n_rays)
 {
-    park_put3(park, kParkTotal, add(park_get3(park, kParkTotal), L.light));
+    f3 total = add(park_get3(park, kParkTotal), L.light);
     uint32_t sample = lane_sample(L) + 1u;
+    if (sample < fp.spp && (int32_t)f2u(park.get(kParkPrimId)) == kNoHit) {
+        // The camera ray missed everything, and every remaining sample starts on that same ray: each
+        // is ray_all -> miss -> light = 0.4 * color with color = 1 (raytracer_compute.wgsl:198-202),
+        // no random draw involved.  Add them here, one by one as the shader's sample loop does,
+        // instead of sending the lane through the shading phase once per sample.
+        f3 sky = add(mk3(0.0f, 0.0f, 0.0f), mul(scale(mk3(1.0f, 1.0f, 1.0f), 0.4f), mk3(1.0f, 1.0f, 1.0f)));
+        for (; sample < fp.spp; sample++) {
+            total = add(total, sky);
+            n_rays.calls++;
+        }
+    }
+    park_put3(park, kParkTotal, total);
     if (sample < fp.spp) {
         L.bits = sample; // bounce 0, no flags: not specular, closest-hit result
         L.color = mk3(1.0f, 1.0f, 1.0f);
