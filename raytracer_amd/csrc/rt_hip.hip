@@ -281,6 +281,7 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
 
     uint32_t ph_inner_it = 0, ph_inner_ln = 0, ph_leaf_it = 0, ph_leaf_ln = 0, ph_shade_it = 0, ph_shade_ln = 0,
              ph_sdone_it = 0, ph_sdone_ln = 0; // COUNT only
+    uint32_t occ_it = 0, occ_inner = 0, occ_leaf = 0, occ_sdone = 0, occ_ready = 0, occ_idle = 0, occ_dead = 0; // COUNT only: lanes per state, summed over traversal turns
     unsigned long long tc_inner = 0, tc_tri = 0, tc_sdone = 0, tc_shade = 0, tc_total = 0, tc0 = 0, tc_begin = 0; // COUNT only: wave cycles per phase
     if (COUNT) tc_begin = clock64();
     bool exhausted = false; // wave-uniform: the global counter has run out
@@ -362,6 +363,15 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
             if (n_ready != 0 && (n_trav + n_sdone) * 8 < (n_trav + n_sdone + n_ready) * sched.shade_num) break;
 
             bool inner = L.mode == rt::kLaneTraverse && rt::link_is_inner(L.cur);
+            if (COUNT) {
+                occ_it++;
+                occ_inner += __popcll(__ballot(inner));
+                occ_leaf += __popcll(__ballot(L.mode == rt::kLaneTraverse && rt::link_is_leaf(L.cur)));
+                occ_sdone += n_sdone;
+                occ_ready += n_ready;
+                occ_idle += __popcll(__ballot(L.mode == rt::kLaneNeedUnit));
+                occ_dead += __popcll(__ballot(L.mode == rt::kLaneDead));
+            }
             if (COUNT) { int n_in = __popcll(__ballot(inner)); if (n_in) { ph_inner_it++; ph_inner_ln += n_in; } tc0 = clock64(); }
             if (inner) rt::lane_step_node(sc, L, stack, cp);
             if (COUNT) tc_inner += clock64() - tc0;
@@ -418,6 +428,13 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
             atomicAdd(fb.counters + 18, tc_sdone);
             atomicAdd(fb.counters + 19, tc_shade);
             atomicAdd(fb.counters + 20, tc_total);
+            atomicAdd(fb.counters + 24, (unsigned long long)occ_it);
+            atomicAdd(fb.counters + 25, (unsigned long long)occ_inner);
+            atomicAdd(fb.counters + 26, (unsigned long long)occ_leaf);
+            atomicAdd(fb.counters + 27, (unsigned long long)occ_sdone);
+            atomicAdd(fb.counters + 28, (unsigned long long)occ_ready);
+            atomicAdd(fb.counters + 29, (unsigned long long)occ_idle);
+            atomicAdd(fb.counters + 30, (unsigned long long)occ_dead);
         }
     }
 }
@@ -806,12 +823,12 @@ int rt_create(int device, int width, int height, int stripe_rows, int stripe_ind
         (e = hipMalloc((void **)&c->fb.accum, px * 3 * sizeof(float))) != hipSuccess ||
         (e = hipMalloc((void **)&c->fb.frame_f16, px * 4 * sizeof(uint16_t))) != hipSuccess ||
         (e = hipMalloc((void **)&c->fb.ids, px * sizeof(int32_t))) != hipSuccess ||
-        (e = hipMalloc((void **)&c->fb.counters, 24 * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->fb.counters, 32 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_work, kWorkCounters * sizeof(unsigned int))) != hipSuccess ||
         (e = hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess ||
         (e = hipMemsetAsync(c->fb.accum, 0, px * 3 * sizeof(float), c->stream)) != hipSuccess ||
         (e = hipMemsetAsync(c->fb.frame_f16, 0, px * 4 * sizeof(uint16_t), c->stream)) != hipSuccess ||
-        (e = hipMemsetAsync(c->fb.counters, 0, 24 * sizeof(unsigned long long), c->stream)) != hipSuccess) {
+        (e = hipMemsetAsync(c->fb.counters, 0, 32 * sizeof(unsigned long long), c->stream)) != hipSuccess) {
         return cleanup(fail(RT_ERR_DEVICE, std::string("rt_create: ") + hipGetErrorString(e)));
     }
     hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, c->stream, c->fb.ids, -2, px);
@@ -1065,15 +1082,17 @@ int rt_set_counting(rt_context *c, int enable)
 }
 
 // Undocumented diagnostic: wave-cycle totals per phase of the instrumented persistent kernel
-// (inner, triangle, shadow hand-over, shade, whole kernel), valid after a counting run.
-int rt_debug_phase_cycles(rt_context *c, uint64_t out[5])
+// (inner, triangle, shadow hand-over, shade, whole kernel) in out[0..4]; out[8] traversal turns and
+// out[9..14] lanes per state summed over them (inner node, leaf, shadow done, ready to shade, idle,
+// dead); valid after a counting run.
+int rt_debug_phase_cycles(rt_context *c, uint64_t out[16])
 {
     if (!c || !out) return fail(RT_ERR_INVALID, "null argument");
     RT_HIP_CHECK(hipSetDevice(c->device));
-    unsigned long long tmp[5];
+    unsigned long long tmp[16];
     RT_HIP_CHECK(hipMemcpyAsync(tmp, c->fb.counters + 16, sizeof tmp, hipMemcpyDeviceToHost, c->stream));
     RT_HIP_CHECK(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 5; i++) out[i] = tmp[i];
+    for (int i = 0; i < 16; i++) out[i] = tmp[i];
     return RT_OK;
 }
 

@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from raytracer_amd import capi, scene as S
 name = sys.argv[1] if len(sys.argv) > 1 else "suzanne"
-W, H, spp, frames = 1920, 1080, 16, 2
+W, H, spp, frames = 1920, 1080, 16, int(os.environ.get("PS_FRAMES", "16"))
 sc = S.load_scene(S.scene_path(name))
 ctx = capi.Context(W, H)
 for k, n in enumerate(["SHADE", "LEAF", "BPC", "BATCH", "SDONE", "REFILL"]):
@@ -20,9 +20,12 @@ for nm, it, ln in (("inner", c[5], c[6]), ("tri", c[7], c[8]), ("shade", c[9], c
     print("%-6s wave-iterations %d  (%.2f per ray-of-wave)  active lanes/iter %.1f (%.0f%%)" % (nm, it, it * 64 / rays, ln / max(it, 1), 100 * ln / max(it, 1) / 64))
 
 import ctypes as C, numpy as np
-out = np.zeros(5, np.uint64)
+out = np.zeros(16, np.uint64)
 fn = ctx.lib.rt_debug_phase_cycles; fn.argtypes = [C.c_void_p, C.c_void_p]; fn.restype = C.c_int
 assert fn(ctx.handle, out.ctypes.data_as(C.c_void_p)) == 0
 tot = float(out[4])
 print("wave-cycle shares: inner %.1f%% tri %.1f%% sdone %.1f%% shade %.1f%% other %.1f%%" % tuple(
     [100 * float(out[i]) / tot for i in range(4)] + [100 * (tot - float(out[:4].sum())) / tot]))
+it = float(out[8])
+if it:
+    print("lanes per state, averaged over traversal turns: inner %.1f leaf %.1f shadow-done %.1f ready-to-shade %.1f idle %.1f dead %.1f" % tuple(float(out[i]) / it for i in range(9, 15)))
