@@ -38,7 +38,6 @@ WIDTH, HEIGHT, SPP, MAX_BOUNCES = 1920, 1080, 16, 6
 PEAK_FP32_TFLOPS = 157.3  # MI355X FP32 vector peak (packed FMA), chip-level spec
 # algorithmic flop prices per test / per bounce ("Roofline accounting")
 F_BOX, F_TRI, F_SPH, F_SHADE = 24, 52, 31, 160
-BATCH_FRAMES = 16  # frames per launch the library chooses for a full 1920x1080 image
 
 
 def parse_args():
@@ -139,6 +138,8 @@ def main():
         ctx.sync()
 
     own = ctx.owned_rows()
+    frames_per_launch = ctx.frames_per_launch()
+    frames_this_rank = sharding.frames_of_rank(1, K * frames_per_step, rank, world)[1] if by_frames else K * frames_per_step
     local_rows = torch.empty((3, own, WIDTH), dtype=torch.float32, device="cuda") if use_dist else None
 
     # warmup (frames 1..W*frames_per_step); the timed run then restarts at frame 1
@@ -240,8 +241,8 @@ def main():
     flops_per_ray = (2 * c_boxpairs * F_BOX + c_tris * F_TRI + c_sph * F_SPH + c_bounces * F_SHADE) / c_rays
     brute_flops_per_ray = F_SPH * len(spheres) + F_TRI * len(tris)
     frames = K * frames_per_step
-    batch = BATCH_FRAMES * world    # frames per launch: the library keeps about 16 x 1920 x 1080 units per launch
-    launches = (frames + batch - 1) // batch
+    batch = frames_per_launch       # frames per kernel launch, as chosen by the library for this context
+    launches = (frames_this_rank + batch - 1) // batch
     rays_per_launch = rays / world / launches
     launch_ms = kernel_ms / launches
     achieved = flops_per_ray * rays_per_launch / (launch_ms * 1e-3) / 1e12

@@ -241,6 +241,10 @@ int rt_export_accum(rt_context *ctx, void *dst_device);
 int rt_import_accum(rt_context *ctx, const void *src_device);
 int rt_finish_frame_sums(rt_context *ctx, uint32_t n_frames_total);
 
+/* How many frames rt_render_frames puts into one kernel launch for this context
+ * (RT_TUNE_BATCH_FRAMES, or the automatic choice), for reports. */
+int rt_frames_per_launch(rt_context *ctx, uint32_t *frames);
+
 /* Acceleration-structure statistics of the current scene, for reports:
  * out[0] nodes, out[1] leaves, out[2] max depth, out[3] bytes on device. */
 int rt_scene_stats(rt_context *ctx, uint64_t out[4]);

@@ -50,6 +50,7 @@ SYMBOLS = {
     "rt_export_accum": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_import_accum": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_finish_frame_sums": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rt_frames_per_launch": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "rt_scene_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 
@@ -217,6 +218,11 @@ class Context:
 
     def finish_frame_sums(self, n_frames_total: int):
         _check(self.lib.rt_finish_frame_sums(self.handle, n_frames_total))
+
+    def frames_per_launch(self) -> int:
+        v = C.c_uint32()
+        _check(self.lib.rt_frames_per_launch(self.handle, C.byref(v)))
+        return v.value
 
     def scene_stats(self) -> dict:
         out = np.zeros(4, dtype=np.uint64)

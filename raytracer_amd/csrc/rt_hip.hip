@@ -587,8 +587,8 @@ struct rt_context {
 namespace {
 
 constexpr uint32_t kWorkCounters = 4096;
-constexpr size_t kBatchBytesCap = (size_t)1 << 30;
-constexpr uint64_t kUnitsPerLaunch = 16ull * 1920 * 1080;
+constexpr size_t kBatchBytesCap = (size_t)2 << 30;
+constexpr uint64_t kUnitsPerLaunch = 64ull * 1920 * 1080;
 
 int launch_tiles(rt_context *c, const rt::FrameParams &fp, bool sum)
 {
@@ -692,21 +692,26 @@ int ensure_slots(rt_context *c)
     return RT_OK;
 }
 
+// Frames per launch of rt_render_frames.  Every launch ends with a tail in which lanes finish their
+// last pixel (16 serial samples, a few ms) while others idle, so launches should be long: by default
+// up to kUnitsPerLaunch (frame, pixel) units, i.e. 64 frames of a 1920x1080 image, more frames when
+// the context owns fewer pixels.  Bounded by the batch buffer size.
+uint32_t frames_per_launch(const rt_context *c)
+{
+    size_t local_px = std::max<size_t>((size_t)c->local_rows * c->width, 1);
+    uint64_t tiles_per_frame = std::max<uint64_t>((uint64_t)((c->width + 7) / 8) * (uint64_t)((c->local_rows + 7) / 8), 1);
+    uint64_t want = c->tune_batch > 0 ? (uint64_t)c->tune_batch
+                                      : std::max<uint64_t>(1, (kUnitsPerLaunch + local_px / 2) / local_px);
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, std::min<uint64_t>(kBatchBytesCap / (local_px * sizeof(uint2)),
+                                                                                  0x7fffffffull / (tiles_per_frame * 64))));
+}
+
 // Frames first, first + stride, ... (n of them) through the persistent kernel, in batches.
 int launch_persistent(rt_context *c, uint32_t first, uint32_t n, uint32_t stride, bool sum)
 {
     size_t local_px = (size_t)c->local_rows * c->width;
     if (local_px == 0 || n == 0) return RT_OK;
-    uint64_t tiles_per_frame = (uint64_t)((c->width + 7) / 8) * (uint64_t)((c->local_rows + 7) / 8);
-    // Frames per launch.  Every launch ends with a tail in which lanes finish their last pixel
-    // (16 serial samples, a few ms) while others idle, so launches should be long: by default
-    // about kUnitsPerLaunch (frame, pixel) units, i.e. 16 frames of a 1920x1080 image, more
-    // frames when the context owns fewer pixels.  Bounded by the batch buffer size.
-    uint64_t want = c->tune_batch > 0 ? (uint64_t)c->tune_batch
-                                      : std::max<uint64_t>(1, (kUnitsPerLaunch + local_px / 2) / local_px);
-    uint32_t max_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want,
-                                                      std::min<uint64_t>(kBatchBytesCap / (local_px * sizeof(uint2)),
-                                                                         0x7fffffffull / (tiles_per_frame * 64))));
+    uint32_t max_batch = frames_per_launch(c);
     uint32_t done = 0;
     while (done < n) {
         uint32_t b = std::min(max_batch, n - done);
@@ -753,8 +758,8 @@ int launch_persistent(rt_context *c, uint32_t first, uint32_t n, uint32_t stride
         } else {
             if (c->batch_capacity < b) {
                 if (c->d_batch) { RT_HIP_CHECK(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_batch); c->d_batch = nullptr; c->batch_capacity = 0; }
-                RT_HIP_CHECK(hipMalloc((void **)&c->d_batch, (size_t)max_batch * local_px * sizeof(uint2)));
-                c->batch_capacity = max_batch;
+                RT_HIP_CHECK(hipMalloc((void **)&c->d_batch, (size_t)b * local_px * sizeof(uint2)));
+                c->batch_capacity = b;
             }
             bp.colors = c->d_batch;
             RT_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned int), c->stream));
@@ -1151,6 +1156,13 @@ int rt_import_rows(rt_context *c, const void *src_device, int from_index)
     hipLaunchKernelGGL(import_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->fb.accum,
                        (const float *)src_device, c->width, c->height, rows, sm);
     RT_HIP_CHECK(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_frames_per_launch(rt_context *c, uint32_t *frames)
+{
+    if (!c || !frames) return fail(RT_ERR_INVALID, "null argument");
+    *frames = frames_per_launch(c);
     return RT_OK;
 }
 
