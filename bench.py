@@ -168,11 +168,14 @@ def main():
             ctx.sync()
     else:
         ctx.render_frames(1, K * frames_per_step)
+    t_render = None
     if use_dist and not by_frames:
         # combine: every rank contributes its rows; rank 0 assembles the image
         ctx.export_owned_rows(local_rows.data_ptr())
         ctx.sync()
-        blocks = sharding.all_gather_rows(local_rows.cpu() if rehearse else local_rows, world)
+        t_render = time.perf_counter() - t0
+        blocks = sharding.all_gather_rows(local_rows.cpu() if rehearse else local_rows, world,
+                                          counts=[len(sharding.owned_rows(HEIGHT, 8, r, world)) for r in range(world)])
         if rank == 0:
             for src, block in enumerate(blocks):
                 if src != 0:
@@ -182,6 +185,8 @@ def main():
             ctx.sync()
     barrier()
     dt = time.perf_counter() - t0
+    if t_render is not None and os.environ.get("RT_BENCH_VERBOSE") == "1":
+        print("rank %d: render %.1f ms, gather + assemble %.1f ms" % (rank, t_render * 1e3, (dt - t_render) * 1e3), file=sys.stderr)
     kernel_ms = ctx.last_render_ms()
     c_after = [int(x) for x in ctx.read_counters()]
     rays = c_after[13] - c_before[13]        # rays actually traversed

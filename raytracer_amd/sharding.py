@@ -31,26 +31,31 @@ def owned_rows(height: int, stripe_rows: int, index: int, count: int) -> np.ndar
     return y[(y // stripe_rows) % count == index]
 
 
-def all_gather_rows(local_block, world: int):
+def all_gather_rows(local_block, world: int, counts=None):
     """All-gather of per-rank row blocks of different heights.
 
     local_block: torch tensor (3, rows_r, width) on the device the process group
     communicates on (CUDA for RCCL, CPU for gloo).  Returns the list of blocks of
-    all ranks.  One collective for the sizes, one for the payload (padded to the
-    tallest block)."""
+    all ranks.  counts: rows per rank when the caller knows them (owned_rows gives
+    them without communication); otherwise one extra collective exchanges them.
+    The payload goes in one collective, padded to the tallest block."""
     import torch
     import torch.distributed as dist
 
-    rows = torch.tensor([local_block.shape[1]], dtype=torch.int64, device=local_block.device)
-    all_rows = [torch.zeros_like(rows) for _ in range(world)]
-    dist.all_gather(all_rows, rows)
-    counts = [int(r.item()) for r in all_rows]
+    if counts is None:
+        rows = torch.tensor([local_block.shape[1]], dtype=torch.int64, device=local_block.device)
+        all_rows = [torch.zeros_like(rows) for _ in range(world)]
+        dist.all_gather(all_rows, rows)
+        counts = [int(r.item()) for r in all_rows]
     tallest = max(counts)
-    padded = torch.zeros((3, tallest, local_block.shape[2]), dtype=local_block.dtype, device=local_block.device)
-    padded[:, : local_block.shape[1]] = local_block
-    out = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(out, padded)
-    return [o[:, :n].contiguous() for o, n in zip(out, counts)]
+    if local_block.shape[1] == tallest:
+        padded = local_block.contiguous()
+    else:
+        padded = torch.zeros((3, tallest, local_block.shape[2]), dtype=local_block.dtype, device=local_block.device)
+        padded[:, : local_block.shape[1]] = local_block
+    out = torch.empty((world,) + tuple(padded.shape), dtype=padded.dtype, device=padded.device)
+    dist.all_gather(list(out.unbind(0)), padded)   # views of one buffer: the collective writes in place
+    return [out[r, :, :n].contiguous() for r, n in enumerate(counts)]
 
 
 def assemble(blocks: List[np.ndarray], height: int, width: int, stripe_rows: int) -> np.ndarray:
