@@ -191,6 +191,8 @@ def main():
     c_after = [int(x) for x in ctx.read_counters()]
     rays = c_after[13] - c_before[13]        # rays actually traversed
     ray_calls = c_after[0] - c_before[0]     # ray_all calls as the reference counts them
+    if os.environ.get("RT_BENCH_VERBOSE") == "1":
+        print("rank %d: %d rays traversed, kernel %.1f ms" % (rank, rays, kernel_ms), file=sys.stderr)
 
     if world > 1 and rank == 0 and os.environ.get("RT_BENCH_VERIFY") == "1" and by_frames:
         ref = capi.Context(WIDTH, HEIGHT, device=device)
