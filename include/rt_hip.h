@@ -4,9 +4,9 @@
  * The reference (guymor4/raytracer) has no FFI layer: its renderer talks to the
  * GPU through the WebGPU objects created in src/webgpu-renderer.ts and
  * src/accumulator.ts.  Each entry point below replaces one of those WebGPU
- * interactions; the comment on it names the lines it stands in for.  The N-API
- * addon (raytracer_amd/js/addon) and the ctypes binding
- * (raytracer_amd/capi.py) bind exactly these symbols.
+ * interactions; the comment on it names the lines it stands in for.  The ctypes
+ * binding (raytracer_amd/capi.py) binds exactly these symbols; the N-API addon
+ * (raytracer_amd/js/addon) binds all but those that take device pointers.
  *
  * Conventions
  *   - every call returns 0 on success, a negative rt_status otherwise;
@@ -56,10 +56,10 @@ typedef enum rt_tuning {
     RT_TUNE_REFILL_LANES = 5,  /* fetch new pixels once this many lanes of a wave are idle (1..64); 0 = by spp   */
     RT_TUNE_MAX_LEAF = 6,      /* triangles per BVH leaf, 1..8; takes effect at the next rt_set_scene           */
     RT_TUNE_TRI_COST_X10 = 7,  /* SAH cost of a triangle test relative to a node visit, in tenths; next rt_set_scene */
-    RT_TUNE_OVERLAP_FRAMES = 9, /* single-frame renders: 1 = trace on alternating side streams so that consecutive
+    RT_TUNE_LDS_STATE = 8,     /* where lanes keep rarely touched state: 2 = in LDS as far as it fits (default), 1 = scenes
+                                  of <= 4096 triangles keep only shadow-ray state there, 0 = all of it in registers    */
+    RT_TUNE_OVERLAP_FRAMES = 9 /* single-frame renders: 1 = trace on alternating side streams so that consecutive
                                   frames overlap (default), 0 = trace and accumulate in one kernel on the context's stream */
-    RT_TUNE_LDS_STATE = 8      /* scenes of <= 4096 triangles: 2 = per-pixel and shadow-ray lane state in LDS (default),
-                                  1 = shadow-ray state only, 0 = all lane state in registers (as for larger scenes)  */
 } rt_tuning;
 
 /* Message of the last failure on the calling thread ("" if none). */
@@ -176,7 +176,7 @@ int rt_read_primary_ids(rt_context *ctx, int32_t *ids);
  *       of a pixel once per frame and reuses its hit for the frame's other
  *       samples, which the shader starts on the same ray
  *       (public/raytracer_compute.wgsl:329-336)
- *   [1] node visits (each tests the two child boxes of one node)
+ *   [1] pairs of box tests (a visit of a 4-wide node counts 2, of a binary node 1)
  *   [2] triangle tests   [3] sphere tests   [4] bounces (shaded hits)
  *   persistent kernel only, per wave: [5] inner-step iterations, [6] lanes active
  *   in them, [7] leaf-step iterations, [8] lanes active in them, [9] shade
