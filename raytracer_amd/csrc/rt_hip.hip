@@ -312,45 +312,43 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
         // that refill together get neighbouring pixels.  A wave takes exactly as many
         // units as it has idle lanes (one atomic for all of them), once enough lanes
         // are idle or nothing else is left to do.
-        for (;;) {
+        // (No loop here: lanes that drew a padding pixel of an edge tile stay idle and ask again on
+        // the next turn of the outer loop, which comes at once when no lane has anything to trace.)
+        {
             unsigned long long need = __ballot(L.mode == rt::kLaneNeedUnit);
-            if (need == 0ull) break;
             uint32_t n_need = (uint32_t)__popcll(need);
-            if (exhausted) {
-                if (L.mode == rt::kLaneNeedUnit) L.mode = rt::kLaneDead;
-                break;
-            }
             bool any_busy = __ballot(L.mode != rt::kLaneNeedUnit && L.mode != rt::kLaneDead) != 0ull;
-            if (any_busy && n_need < (uint32_t)sched.refill_lanes) break;
-            unsigned int base = 0;
-            if (lane == 0) base = atomicAdd(work_counter, n_need);
-            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-            if (base + n_need >= total_units) exhausted = true;
-            uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-            if (L.mode == rt::kLaneNeedUnit) {
-                uint32_t unit = base + rank;
-                if (unit >= total_units) {
-                    L.mode = rt::kLaneDead;
-                } else {
-                    uint32_t tile_all = unit >> 6, slot = unit & 63u;
-                    uint32_t frame_k = tile_all / tiles_per_frame, tile = tile_all % tiles_per_frame;
-                    int px = (int)((tile % tiles_x) * 8u + (slot & 7u));
-                    int ly = (int)((tile / tiles_x) * 8u + (slot >> 3));
-                    int py = stripe_global_row(sm, ly);
-                    if (px < fp.width && ly < local_rows && py < fp.height) {
-                        L.unit = unit;
-                        if (fp.max_bounces == 0u) {
-                            rt::lane_empty_pixel(L, park);
-                        } else {
-                            rt::FrameParams f = fp;
-                            if (!FUSED) f.seed_add = (uint32_t)(float)(bp.first_frame + frame_k * bp.stride) * 12345u;
-                            rt::lane_begin_pixel(sc, f, L, px, py, stack, park, n_rays, cp);
+            if (need != 0ull && exhausted) {
+                if (L.mode == rt::kLaneNeedUnit) L.mode = rt::kLaneDead;
+            } else if (need != 0ull && (!any_busy || n_need >= (uint32_t)sched.refill_lanes)) {
+                unsigned int base = 0;
+                if (lane == 0) base = atomicAdd(work_counter, n_need);
+                base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+                if (base + n_need >= total_units) exhausted = true;
+                uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                if (L.mode == rt::kLaneNeedUnit) {
+                    uint32_t unit = base + rank;
+                    if (unit >= total_units) {
+                        L.mode = rt::kLaneDead;
+                    } else {
+                        uint32_t tile_all = unit >> 6, slot = unit & 63u;
+                        uint32_t frame_k = tile_all / tiles_per_frame, tile = tile_all % tiles_per_frame;
+                        int px = (int)((tile % tiles_x) * 8u + (slot & 7u));
+                        int ly = (int)((tile / tiles_x) * 8u + (slot >> 3));
+                        int py = stripe_global_row(sm, ly);
+                        if (px < fp.width && ly < local_rows && py < fp.height) {
+                            L.unit = unit;
+                            if (fp.max_bounces == 0u) {
+                                rt::lane_empty_pixel(L, park);
+                            } else {
+                                rt::FrameParams f = fp;
+                                if (!FUSED) f.seed_add = (uint32_t)(float)(bp.first_frame + frame_k * bp.stride) * 12345u;
+                                rt::lane_begin_pixel(sc, f, L, px, py, stack, park, n_rays, cp);
+                            }
                         }
                     }
                 }
             }
-            if (!any_busy) continue; // padding pixels of edge tiles leave lanes idle: ask again
-            break;
         }
         if (__ballot(L.mode != rt::kLaneDead) == 0ull) break;
 
