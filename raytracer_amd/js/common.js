@@ -1,125 +1,143 @@
 'use strict';
 /*
- * Scene loading for Node: loadScene / loadOBJ / parseOBJ with the behaviour of
- * the reference's src/common.ts:34-148, reading files instead of fetching
- * URLs.  Plain JS that Node 12 parses (no optional chaining, no global fetch).
+ * Scene files for a Node host: loadScene / loadOBJ / parseOBJ / showError /
+ * RethrownError / formatNumber, behaving as the functions of the same names in
+ * the reference's src/common.ts:3-158, with files read from disk where the
+ * reference fetches URLs.  Plain CommonJS that Node 12 parses.
  */
 const fs = require('fs');
 const path = require('path');
+const util = require('util');
 
-// src/common.ts:3-10 without a DOM: the message goes to stderr.
+const readText = util.promisify(fs.readFile);
+
+// The five fields a model hands to its triangles (src/common.ts:131-137); a model's position,
+// rotation and scale are read and ignored there, so they are here.
+const MATERIAL_KEYS = ['color', 'emissionColor', 'emissionStrength', 'smoothness', 'specularProbability'];
+
+const DEFAULT_MATERIAL = {
+    color: [1, 1, 1], emissionColor: [0, 0, 0], emissionStrength: 0, smoothness: 0, specularProbability: 0,
+};
+
+/* src/common.ts:3-10 shows the message in the page; a headless host writes it to stderr. */
 function showError(message) {
-    console.error('HIP Error:', message);
+    process.stderr.write('HIP Error: ' + message + '\n');
 }
 
-// src/common.ts:12-32
+/*
+ * An error that keeps the one it wraps (src/common.ts:12-32): `original_error`, the stack before
+ * wrapping in `stack_before_rethrow`, and a stack made of this error's head (message lines + one
+ * frame) followed by the wrapped error's stack.
+ */
 class RethrownError extends Error {
     constructor(message, error) {
         super(message);
-        this.name = this.constructor.name;
         if (!error) throw new Error('RethrownError requires a message and error');
+        this.name = 'RethrownError';
         this.original_error = error;
         this.stack_before_rethrow = this.stack;
-        const messageLines = (this.message.match(/\n/g) || []).length + 1;
-        this.stack =
-            (this.stack ? this.stack.split('\n').slice(0, messageLines + 1).join('\n') : '') +
-            '\n' + error.stack;
+        const own = String(this.stack || '').split('\n');
+        const keep = String(message).split('\n').length + 1;
+        this.stack = own.slice(0, keep).concat([error.stack]).join('\n');
     }
 }
 
-// src/common.ts:45-109.  Quirks kept: split on '\n' and trim; faces split on a
-// single space; a face vertex needs a position and a normal index (v//vn or
-// v/vt/vn) or it is skipped; out-of-range indices are skipped with a warning;
-// fan triangulation.
+function numbersAfterKeyword(line) {
+    const words = line.split(/\s+/);
+    return [parseFloat(words[1]), parseFloat(words[2]), parseFloat(words[3])];
+}
+
+/*
+ * One corner "v/vt/vn" of a face -> its position, or UNUSABLE when the corner cannot be used:
+ * it needs a position index and a normal index (so "v" and "v/vt" are not enough), and both have
+ * to point at something already read (1-based).
+ */
+const UNUSABLE = {};
+
+function cornerPosition(corner, positions, normalCount) {
+    const fields = corner.split('/');
+    if (!fields[0] || !fields[2]) return UNUSABLE;
+    const v = parseInt(fields[0], 10);
+    const n = parseInt(fields[2], 10);
+    if (v < 1 || v > positions.length || n < 1 || n > normalCount) {
+        console.warn('Invalid index in face definition: ' + corner);
+        return UNUSABLE;
+    }
+    return positions[v - 1]; // an index that is not a number passes the range test, as in the reference, and yields undefined
+}
+
+/*
+ * Wavefront OBJ -> triangles (src/common.ts:45-109).  Lines are cut at "\n" and trimmed; "v" and
+ * "vn" take three numbers; a face's corners are separated by exactly one space and a polygon
+ * becomes a fan around its first corner.  Corners that cannot be used are left out, which leaves
+ * that triangle with fewer than three vertices (v2, or all of them, undefined), as the reference
+ * does; such a triangle fails later, when the scene is packed.
+ */
 function parseOBJ(objText) {
+    const positions = [];
+    let normalCount = 0;
     const triangles = [];
-    const tempPositions = [];
-    const tempNormals = [];
-    const lines = objText.split('\n');
-    for (let line of lines) {
-        line = line.trim();
+    objText.split('\n').forEach((raw) => {
+        const line = raw.trim();
         if (line.startsWith('v ')) {
-            const p = line.split(/\s+/);
-            tempPositions.push([parseFloat(p[1]), parseFloat(p[2]), parseFloat(p[3])]);
+            positions.push(numbersAfterKeyword(line));
         } else if (line.startsWith('vn ')) {
-            const p = line.split(/\s+/);
-            tempNormals.push([parseFloat(p[1]), parseFloat(p[2]), parseFloat(p[3])]);
+            normalCount += 1;
         } else if (line.startsWith('f ')) {
-            const parts = line.slice(2).trim().split(' ');
-            if (parts.length < 3) continue;
-            for (let i = 1; i < parts.length - 1; i++) {
-                const triangleVertices = [];
-                for (const fv of [parts[0], parts[i], parts[i + 1]]) {
-                    const idx = fv.split('/').map((x) => (x ? parseInt(x) : undefined));
-                    const vIdx = idx[0];
-                    const nIdx = idx[2];
-                    if (vIdx === undefined || nIdx === undefined) continue;
-                    if (vIdx < 1 || vIdx > tempPositions.length || nIdx < 1 || nIdx > tempNormals.length) {
-                        console.warn('Invalid index in face definition: ' + fv);
-                        continue;
-                    }
-                    triangleVertices.push(tempPositions[vIdx - 1]);
-                }
-                triangles.push({
-                    v0: triangleVertices[0],
-                    v1: triangleVertices[1],
-                    v2: triangleVertices[2],
-                    color: [1, 1, 1],
-                    emissionColor: [0, 0, 0],
-                    emissionStrength: 0,
-                    smoothness: 0,
-                    specularProbability: 0,
-                });
+            const corners = line.slice(2).trim().split(' ');
+            for (let k = 2; k < corners.length; k++) {
+                const found = [corners[0], corners[k - 1], corners[k]]
+                    .map((c) => cornerPosition(c, positions, normalCount))
+                    .filter((p) => p !== UNUSABLE);
+                triangles.push(Object.assign({ v0: found[0], v1: found[1], v2: found[2] }, DEFAULT_MATERIAL));
             }
         }
-    }
-    return { triangles: triangles };
+    });
+    return { triangles };
 }
 
-// src/common.ts:34-43
+/* src/common.ts:34-43 with a file path in place of a URL. */
 async function loadOBJ(file) {
-    const text = await fs.promises.readFile(file, 'utf8');
-    const result = parseOBJ(text);
-    console.log('Loaded OBJ from ' + file + ': ' + result.triangles.length + ' triangles');
-    return result;
+    const parsed = parseOBJ(await readText(file, 'utf8'));
+    console.log('Loaded OBJ from ' + file + ': ' + parsed.triangles.length + ' triangles');
+    return parsed;
 }
 
-// src/common.ts:111-148.  Model paths resolve against the scene file's
-// directory.  position / rotation / scale of a model are not applied, as in
-// the reference; only the five material fields are copied.
+/*
+ * Scene JSON -> { camera, spheres, triangles } (src/common.ts:111-148).  Each model's OBJ file is
+ * looked up next to the scene file (the reference serves both from public/), its triangles get the
+ * model's material and are appended after the scene's own triangles, in model order.  A model
+ * that cannot be loaded is reported and skipped.
+ */
 async function loadScene(scenePath) {
-    let text;
+    let raw;
     try {
-        text = await fs.promises.readFile(scenePath, 'utf8');
+        raw = JSON.parse(await readText(scenePath, 'utf8'));
     } catch (e) {
         throw new Error('Failed to load scene file: ' + e.message);
     }
-    const scene = JSON.parse(text);
-    const base = path.dirname(path.resolve(scenePath));
-    for (const model of scene.models || []) {
-        if (model.path) {
-            try {
-                const objData = await loadOBJ(path.join(base, model.path));
-                for (const triangle of objData.triangles) {
-                    scene.triangles.push(Object.assign({}, triangle, {
-                        color: model.color,
-                        emissionColor: model.emissionColor,
-                        emissionStrength: model.emissionStrength,
-                        smoothness: model.smoothness,
-                        specularProbability: model.specularProbability,
-                    }));
-                }
-            } catch (error) {
-                console.error('Failed to load model from ' + model.path + ':', error);
-            }
+    const folder = path.dirname(path.resolve(scenePath));
+    const triangles = raw.triangles;
+    for (const model of raw.models || []) {
+        if (!model.path) continue;
+        try {
+            const mesh = await loadOBJ(path.join(folder, model.path));
+            mesh.triangles.forEach((t) => {
+                const copy = Object.assign({}, t);
+                MATERIAL_KEYS.forEach((key) => { copy[key] = model[key]; });
+                triangles.push(copy);
+            });
+        } catch (error) {
+            console.error('Failed to load model from ' + model.path + ':', error);
         }
     }
-    return { camera: scene.camera, spheres: scene.spheres, triangles: scene.triangles };
+    return { camera: raw.camera, spheres: raw.spheres, triangles };
 }
 
-// src/common.ts:150-158
-function formatNumber(num) {
-    return new Intl.NumberFormat('en-US', { notation: 'compact', compactDisplay: 'short', maximumFractionDigits: 2 }).format(num);
+/* 1234567 -> "1.23M" (src/common.ts:150-158). */
+function formatNumber(value) {
+    const compact = new Intl.NumberFormat('en-US', { notation: 'compact', compactDisplay: 'short', maximumFractionDigits: 2 });
+    return compact.format(value);
 }
 
 module.exports = { showError, RethrownError, parseOBJ, loadOBJ, loadScene, formatNumber };

@@ -1,28 +1,31 @@
 'use strict';
-// src/fps-counter.ts:1-21 with perf_hooks instead of the browser's performance object.
-const { performance } = require('perf_hooks');
+/*
+ * Frames-per-second meter with the interface of the reference's FPSCounter
+ * (src/fps-counter.ts): updateFPS() once per loop tick, getFPS() for the last
+ * completed window.  A window closes at the first tick that comes at least one
+ * second after it opened; its rate is ticks * 1000 / elapsed ms, rounded.
+ */
+const clock = require('perf_hooks').performance;
 
-class FPSCounter {
-    constructor() {
-        this.frameCount = 0;
-        this.lastTime = performance.now();
-        this.currentFPS = 0;
-    }
+const WINDOW_MS = 1000;
 
-    updateFPS() {
-        this.frameCount++;
-        const currentTime = performance.now();
-        const deltaTime = currentTime - this.lastTime;
-        if (deltaTime >= 1000) {
-            this.currentFPS = Math.round((this.frameCount * 1000) / deltaTime);
-            this.frameCount = 0;
-            this.lastTime = currentTime;
-        }
-    }
+function FPSCounter() {
+    let windowStart = clock.now();
+    let ticks = 0;
+    let rate = 0;
 
-    getFPS() {
-        return this.currentFPS;
-    }
+    this.updateFPS = function () {
+        ticks += 1;
+        const elapsed = clock.now() - windowStart;
+        if (elapsed < WINDOW_MS) return;
+        rate = Math.round(ticks * WINDOW_MS / elapsed);
+        windowStart += elapsed;
+        ticks = 0;
+    };
+
+    this.getFPS = function () {
+        return rate;
+    };
 }
 
 module.exports = { FPSCounter };
