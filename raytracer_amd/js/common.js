@@ -104,12 +104,31 @@ async function loadOBJ(file) {
 }
 
 /*
+ * A model vertex under the model's scale, rotation (degrees about x, then y, then z) and position,
+ * in that order.  The reference declares these fields (src/types.ts:34-39) and never applies them;
+ * this is an opt-in extension with a convention of its own.
+ */
+function transformPoint(p, model) {
+    const s = model.scale || [1, 1, 1], r = model.rotation || [0, 0, 0], t = model.position || [0, 0, 0];
+    const rad = (deg) => deg * Math.PI / 180;
+    let x = p[0] * s[0], y = p[1] * s[1], z = p[2] * s[2];
+    const cx = Math.cos(rad(r[0])), sx = Math.sin(rad(r[0]));
+    [y, z] = [y * cx - z * sx, y * sx + z * cx];
+    const cy = Math.cos(rad(r[1])), sy = Math.sin(rad(r[1]));
+    [x, z] = [x * cy + z * sy, -x * sy + z * cy];
+    const cz = Math.cos(rad(r[2])), sz = Math.sin(rad(r[2]));
+    [x, y] = [x * cz - y * sz, x * sz + y * cz];
+    return [x + t[0], y + t[1], z + t[2]];
+}
+
+/*
  * Scene JSON -> { camera, spheres, triangles } (src/common.ts:111-148).  Each model's OBJ file is
  * looked up next to the scene file (the reference serves both from public/), its triangles get the
  * model's material and are appended after the scene's own triangles, in model order.  A model
- * that cannot be loaded is reported and skipped.
+ * that cannot be loaded is reported and skipped.  options.applyModelTransforms (off by default: it
+ * changes the image) sends the model's vertices through transformPoint.
  */
-async function loadScene(scenePath) {
+async function loadScene(scenePath, options) {
     let raw;
     try {
         raw = JSON.parse(await readText(scenePath, 'utf8'));
@@ -124,6 +143,9 @@ async function loadScene(scenePath) {
             const mesh = await loadOBJ(path.join(folder, model.path));
             mesh.triangles.forEach((t) => {
                 const copy = Object.assign({}, t);
+                if (options && options.applyModelTransforms) {
+                    ['v0', 'v1', 'v2'].forEach((key) => { copy[key] = transformPoint(copy[key], model); });
+                }
                 MATERIAL_KEYS.forEach((key) => { copy[key] = model[key]; });
                 triangles.push(copy);
             });
@@ -140,4 +162,4 @@ function formatNumber(value) {
     return compact.format(value);
 }
 
-module.exports = { showError, RethrownError, parseOBJ, loadOBJ, loadScene, formatNumber };
+module.exports = { showError, RethrownError, parseOBJ, loadOBJ, loadScene, transformPoint, formatNumber };

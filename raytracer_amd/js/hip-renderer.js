@@ -41,7 +41,8 @@ class HipRenderer {
     }
 
     // src/webgpu-renderer.ts:48-103.  options: { device, maxBounces, stripeRows, stripeIndex, stripeCount,
-    // presentEvery }: presentEvery = k copies the image into canvas.pixels on every k-th frame only (default 1,
+    // presentEvery, applyModelTransforms }: applyModelTransforms applies a model's scale / rotation / position, which the
+    // reference reads and ignores (off by default); presentEvery = k copies the image into canvas.pixels on every k-th frame only (default 1,
     // every frame as the reference's canvas pass does; the copy reads the accumulator back and so waits for the GPU)
     static async Create(canvas, scenePath, options) {
         const renderer = new HipRenderer(canvas);
@@ -59,7 +60,7 @@ class HipRenderer {
                 throw new RethrownError('Failed to create pipelines', error);
             }
             try {
-                renderer.currentScene = await Common.loadScene(scenePath);
+                renderer.currentScene = await Common.loadScene(scenePath, { applyModelTransforms: !!opt.applyModelTransforms });
             } catch (error) {
                 throw new RethrownError("Failed to load '" + scenePath + "'", error);
             }

@@ -115,7 +115,23 @@ def parse_obj(obj_text: str) -> List[dict]:
     return triangles
 
 
-def load_scene(scene_path: str) -> Scene:
+def transform_point(p: Sequence[float], model: dict) -> List[float]:
+    """A model vertex under the model's ``scale``, ``rotation`` (degrees about x, then y, then z) and
+    ``position``, in that order.  The reference declares these fields (src/types.ts:34-39) and never
+    applies them, so this is an extension with a convention of its own; see ``load_scene``."""
+    import math
+
+    sx, sy, sz = model.get("scale", [1, 1, 1])
+    rx, ry, rz = (math.radians(a) for a in model.get("rotation", [0, 0, 0]))
+    tx, ty, tz = model.get("position", [0, 0, 0])
+    x, y, z = p[0] * sx, p[1] * sy, p[2] * sz
+    y, z = y * math.cos(rx) - z * math.sin(rx), y * math.sin(rx) + z * math.cos(rx)
+    x, z = x * math.cos(ry) + z * math.sin(ry), -x * math.sin(ry) + z * math.cos(ry)
+    x, y = x * math.cos(rz) - y * math.sin(rz), x * math.sin(rz) + y * math.cos(rz)
+    return [x + tx, y + ty, z + tz]
+
+
+def load_scene(scene_path: str, apply_model_transforms: bool = False) -> Scene:
     """src/common.ts:111-148.
 
     Model paths resolve against the scene file's directory (the reference
@@ -123,6 +139,11 @@ def load_scene(scene_path: str) -> Scene:
     ``position``/``rotation``/``scale`` are read and ignored, as in the
     reference; only the five material fields are copied onto OBJ triangles.
     A model that fails to load is skipped (the reference logs and continues).
+
+    ``apply_model_transforms=True`` is an opt-in extension: the model's vertices
+    go through ``transform_point``.  Off by default because it changes the image
+    (scene_suzanne.json asks for half size at (1, 0, -3); the reference shows the
+    model full size at the origin).
     """
     with open(scene_path, "r") as fh:
         raw = json.load(fh)
@@ -139,6 +160,9 @@ def load_scene(scene_path: str) -> Scene:
             continue
         for tri in obj_tris:
             t = dict(tri)
+            if apply_model_transforms:
+                for key in ("v0", "v1", "v2"):
+                    t[key] = transform_point(t[key], model)
             for key in ("color", "emissionColor", "emissionStrength", "smoothness", "specularProbability"):
                 t[key] = model[key]
             triangles.append(t)

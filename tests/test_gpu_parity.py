@@ -372,3 +372,10 @@ def test_python_renderer_mirror(scenes, tmp_path):
     assert np.array_equal(r.read_accum(), orc.accum_rgb())
     r.close()
     r.render()                               # no resources: silent no-op (src/webgpu-renderer.ts:238-246)
+
+
+def test_scene_with_model_transforms_applied():
+    """The opt-in loader extension that applies a model's scale / rotation / position (scene_suzanne's
+    model at half size near the back wall): new geometry for the renderer, same parity bar."""
+    scene = S.load_scene(S.scene_path("suzanne"), apply_model_transforms=True)
+    run_pair(scene, 96, 54, 2, 3, capi.RT_MODE_BVH)

@@ -42,6 +42,22 @@ C.loadScene(process.argv[1]).then((s) => {
     assert np.array_equal(np.fromfile(tmp_path / "o.un", np.float32), S.pack_uniforms(sc.camera, 7, 640, 360, 16, True))
 
 
+def test_js_model_transform_extension_matches_python(tmp_path):
+    script = """
+const C = require('%s/common'), G = require('%s/gpu-schemas'), fs = require('fs');
+C.loadScene(process.argv[1], { applyModelTransforms: true }).then((s) => {
+  fs.writeFileSync(process.argv[2], Buffer.from(G.packTriangles(s.triangles).buffer));
+  console.log(JSON.stringify(C.transformPoint([1, 2, 3], { scale: [2, 1, 1], rotation: [10, 20, 30], position: [0.5, 0, -1] })));
+});
+""" % (JS, JS)
+    out = node(script, S.scene_path("suzanne"), str(tmp_path / "t.bin"))
+    sc = S.load_scene(S.scene_path("suzanne"), apply_model_transforms=True)
+    got = np.fromfile(tmp_path / "t.bin", np.float32).reshape(-1, 24)
+    assert np.allclose(got, S.pack_triangles(sc.triangles), atol=1e-6)
+    py = S.transform_point([1, 2, 3], dict(scale=[2, 1, 1], rotation=[10, 20, 30], position=[0.5, 0, -1]))
+    assert np.allclose(json.loads(out.strip().splitlines()[-1]), py, atol=1e-12)
+
+
 def test_js_obj_parser_quirks():
     script = """
 const C = require('%s/common');

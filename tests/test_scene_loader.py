@@ -70,3 +70,19 @@ def test_js_number_parsing():
     assert S.js_parse_float("1e-3x") == 1e-3
     assert S.js_parse_float("abc") != S.js_parse_float("abc")
     assert S.js_parse_int("12abc") == 12 and S.js_parse_int("") is None and S.js_parse_int("-3") == -3
+
+
+def test_model_transforms_are_opt_in(scenes):
+    """The extension that applies a model's scale / rotation / position: off by default (the image the
+    reference produces), and when on, scene_suzanne's model ends up half size around (1, 0, -3)."""
+    plain = S.load_scene(S.scene_path("suzanne"))
+    assert plain.triangles[14:] == scenes["suzanne"].triangles[14:]
+    moved = S.load_scene(S.scene_path("suzanne"), apply_model_transforms=True)
+    a = np.array([[t["v0"], t["v1"], t["v2"]] for t in plain.triangles[14:]], np.float64)
+    b = np.array([[t["v0"], t["v1"], t["v2"]] for t in moved.triangles[14:]], np.float64)
+    assert np.allclose(b, a * 0.5 + np.array([1.0, 0.0, -3.0]), atol=1e-12)
+    assert moved.triangles[:14] == plain.triangles[:14]
+    model = dict(scale=[2, 1, 1], rotation=[0, 90, 0], position=[0, 0, 1])
+    assert np.allclose(S.transform_point([1, 2, 3], model), [3, 2, -2 + 1], atol=1e-12)
+    assert np.allclose(S.transform_point([1, 0, 0], dict(rotation=[0, 0, 90])), [0, 1, 0], atol=1e-12)
+    assert np.allclose(S.transform_point([0, 1, 0], dict(rotation=[90, 0, 0])), [0, 0, 1], atol=1e-12)
