@@ -117,7 +117,9 @@ class HipRenderer {
         this.frameIndex += n;
         this.native.renderFrames(this.handle, first, n);
         this.writeUniforms();
-        this.accumulator.render(null, this.canvas.pixels);
+        const every = this.presentEvery || 1;
+        const present = this.canvas.pixels && Math.floor(this.frameIndex / every) > Math.floor((first - 1) / every);
+        this.accumulator.render(null, present ? this.canvas.pixels : null);
     }
 
     // src/webgpu-renderer.ts:270-277 with setImmediate in place of requestAnimationFrame

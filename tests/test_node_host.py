@@ -58,6 +58,39 @@ C.loadScene(process.argv[1], { applyModelTransforms: true }).then((s) => {
     assert np.allclose(json.loads(out.strip().splitlines()[-1]), py, atol=1e-12)
 
 
+def test_png_and_ppm_encoders(tmp_path):
+    """image-writer.js: a 5x3 RGBA image through both encoders; the PNG is decoded here by hand
+    (signature, IHDR, one zlib stream of filter-0 scanlines, chunk CRCs)."""
+    import struct
+    import zlib
+
+    script = """
+const W = require('%s/image-writer'), fs = require('fs');
+const px = new Uint8Array(5 * 3 * 4);
+for (let i = 0; i < px.length; i++) px[i] = (i * 37 + 11) & 255;
+W.writeImage(process.argv[1] + '.png', px, 5, 3);
+W.writeImage(process.argv[1] + '.ppm', px, 5, 3);
+""" % JS
+    node(script, str(tmp_path / "img"))
+    rgba = ((np.arange(60) * 37 + 11) & 255).astype(np.uint8).reshape(3, 5, 4)
+    ppm = (tmp_path / "img.ppm").read_bytes()
+    assert ppm == b"P6\n5 3\n255\n" + rgba[:, :, :3].tobytes()
+    png = (tmp_path / "img.png").read_bytes()
+    assert png[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(png):
+        (length,) = struct.unpack(">I", png[pos:pos + 4])
+        tag, data = png[pos + 4:pos + 8], png[pos + 8:pos + 8 + length]
+        (crc,) = struct.unpack(">I", png[pos + 8 + length:pos + 12 + length])
+        assert crc == zlib.crc32(tag + data) & 0xFFFFFFFF
+        chunks.append((tag, data))
+        pos += 12 + length
+    assert [t for t, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    assert struct.unpack(">IIBBBBB", chunks[0][1]) == (5, 3, 8, 2, 0, 0, 0)
+    rows = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(3, 1 + 5 * 3)
+    assert (rows[:, 0] == 0).all() and np.array_equal(rows[:, 1:].reshape(3, 5, 3), rgba[:, :, :3])
+
+
 def test_js_obj_parser_quirks():
     script = """
 const C = require('%s/common');
@@ -95,7 +128,7 @@ def test_js_renderer_matches_oracle(scenes, tmp_path, per_frame):
     width, height, frames, spp = 96, 54, 3, 4
     args = [NODE, os.path.join(JS, "cli.js"), "--scene", S.scene_path("suzanne"), "--width", str(width), "--height",
             str(height), "--spp", str(spp), "--frames", str(frames), "--dump", str(tmp_path / "d"), "--ppm",
-            str(tmp_path / "img.ppm")] + (["--per-frame"] if per_frame else [])
+            str(tmp_path / "img.ppm"), "--preview-every", "2"] + (["--per-frame"] if per_frame else [])
     out = subprocess.run(args, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     info = json.loads(out.stdout.strip().splitlines()[-1])
