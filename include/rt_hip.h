@@ -58,8 +58,11 @@ typedef enum rt_tuning {
     RT_TUNE_TRI_COST_X10 = 7,  /* SAH cost of a triangle test relative to a node visit, in tenths; next rt_set_scene */
     RT_TUNE_LDS_STATE = 8,     /* where lanes keep rarely touched state: 2 = in LDS as far as it fits (default), 1 = scenes
                                   of <= 4096 triangles keep only shadow-ray state there, 0 = all of it in registers    */
-    RT_TUNE_OVERLAP_FRAMES = 9 /* single-frame renders: 1 = trace on alternating side streams so that consecutive
+    RT_TUNE_SHADE_WAIT = 10,   /* shade finished lanes anyway once they have waited this many traversal turns
+                                  (default 12); 0 = never */
+    RT_TUNE_OVERLAP_FRAMES = 9, /* single-frame renders: 1 = trace on alternating side streams so that consecutive
                                   frames overlap (default), 0 = trace and accumulate in one kernel on the context's stream */
+    RT_TUNE_END
 } rt_tuning;
 
 /* Message of the last failure on the calling thread ("" if none). */

@@ -237,6 +237,7 @@ struct SchedParams {
     int leaf_lanes;   // visit leaves when at least this many lanes wait at one (or no lane is at an inner node)
     int sdone_lanes;  // finish shadow rays when at least this many lanes wait for it (or no lane is traversing)
     int refill_lanes; // fetch new pixels when at least this many lanes are idle (or the whole wave is)
+    int shade_wait;   // shade anyway once finished lanes have waited this many traversal turns (0: never)
 };
 
 struct BatchParams {
@@ -353,12 +354,15 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
         if (__ballot(L.mode != rt::kLaneDead) == 0ull) break;
 
         // ---- traversal steps ----------------------------------------------------------------
+        int turns_waiting = 0; // turns of this loop during which finished lanes have been waiting to be shaded
         for (;;) {
             int n_trav = __popcll(__ballot(L.mode == rt::kLaneTraverse));
             int n_sdone = __popcll(__ballot(L.mode == rt::kLaneShadowDone));
             if (n_trav + n_sdone == 0) break;
             int n_ready = __popcll(__ballot(L.mode == rt::kLaneShadeClosest || L.mode == rt::kLanePixelDone));
             if (n_ready != 0 && (n_trav + n_sdone) * 8 < (n_trav + n_sdone + n_ready) * sched.shade_num) break;
+            // long traversals of a few lanes must not hold the finished ones for ever
+            if (n_ready != 0 && sched.shade_wait > 0 && ++turns_waiting >= sched.shade_wait) break;
 
             bool inner = L.mode == rt::kLaneTraverse && rt::link_is_inner(L.cur);
             if (COUNT) {
@@ -572,6 +576,7 @@ struct rt_context {
     size_t spill_bytes[3] = {0, 0, 0};
     int next_slot = 0;
     int tune_overlap = 1;
+    int tune_shade_wait = 12;
     int tune_shade_num = 2, tune_leaf_lanes = 12, tune_blocks_per_cu = 0, tune_batch = 0, tune_sdone_lanes = 2, tune_refill_lanes = 0, tune_max_leaf = 4, tune_tri_cost_x10 = 12, tune_lds_state = RT_LDS_PARK;
 
     void free_scene()
@@ -644,7 +649,7 @@ int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchPar
     // often, so more idle lanes are collected before a refill (measured optimum per spp).
     int refill = c->tune_refill_lanes;
     if (refill <= 0) refill = fp.spp <= 1u ? 32 : fp.spp <= 2u ? 24 : fp.spp <= 4u ? 16 : fp.spp <= 8u ? 8 : 4;
-    SchedParams sched{c->tune_shade_num, c->tune_leaf_lanes, c->tune_sdone_lanes, refill};
+    SchedParams sched{c->tune_shade_num, c->tune_leaf_lanes, c->tune_sdone_lanes, refill, c->tune_shade_wait};
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, c->view, fp, c->sm, c->local_rows, c->fb,
                        bp, counter, sched, spill);
     RT_HIP_CHECK(hipGetLastError());
@@ -937,6 +942,7 @@ int rt_set_tuning(rt_context *c, int key, int value)
     case RT_TUNE_TRI_COST_X10: if (value < 1 || value > 1000) return fail(RT_ERR_INVALID, "tri_cost out of range"); c->tune_tri_cost_x10 = value; break;
     case RT_TUNE_REFILL_LANES: if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "refill_lanes out of range"); c->tune_refill_lanes = value; break;
     case RT_TUNE_OVERLAP_FRAMES: if (value < 0 || value > 1) return fail(RT_ERR_INVALID, "overlap_frames out of range"); c->tune_overlap = value; break;
+    case RT_TUNE_SHADE_WAIT: if (value < 0 || value > 1000) return fail(RT_ERR_INVALID, "shade_wait out of range"); c->tune_shade_wait = value; break;
     case RT_TUNE_LDS_STATE: if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "lds_state out of range"); c->tune_lds_state = value; break;
     case RT_TUNE_SHADOW_DONE_LANES: if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "shadow_done_lanes out of range"); c->tune_sdone_lanes = value; break;
     default: return fail(RT_ERR_INVALID, "unknown tuning key");

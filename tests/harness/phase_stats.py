@@ -4,11 +4,23 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from raytracer_amd import capi, scene as S
 name = sys.argv[1] if len(sys.argv) > 1 else "suzanne"
 W, H, spp, frames = 1920, 1080, 16, int(os.environ.get("PS_FRAMES", "16"))
-sc = S.load_scene(S.scene_path(name))
+if name.startswith("hf"):      # hf256: height field of 256 x 256 quads
+    from tests.synth import heightfield_scene
+    sc = heightfield_scene(int(name[2:]))
+    packed = (S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles))
+elif name.startswith("sub"):   # sub5: suzanne with its model split 5 times
+    from tests.synth import subdivided_suzanne_packed
+    cam, sp, tr = subdivided_suzanne_packed(int(name[3:]))
+    sc = S.Scene(camera=cam)
+    packed = (sp, tr)
+else:
+    sc = S.load_scene(S.scene_path(name))
+    packed = (S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles))
 ctx = capi.Context(W, H)
+if "PS_BOUNCES" in os.environ: ctx.set_max_bounces(int(os.environ["PS_BOUNCES"]))
 for k, n in enumerate(["SHADE", "LEAF", "BPC", "BATCH", "SDONE", "REFILL"]):
     if "RT_" + n in os.environ: ctx.set_tuning(k, int(os.environ["RT_" + n]))
-ctx.set_scene(S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles))
+ctx.set_scene(*packed)
 ctx.set_counting(True)
 ctx.set_uniforms(S.pack_uniforms(sc.camera, 1, W, H, spp))
 ctx.render_frames(1, frames); ctx.sync()
