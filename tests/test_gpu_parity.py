@@ -381,3 +381,26 @@ def test_scene_with_model_transforms_applied():
     model at half size near the back wall): new geometry for the renderer, same parity bar."""
     scene = S.load_scene(S.scene_path("suzanne"), apply_model_transforms=True)
     run_pair(scene, 96, 54, 2, 3, capi.RT_MODE_BVH)
+
+
+def test_five_thousand_single_frames(scenes):
+    """More single-frame submissions than the library has per-launch work counters (4096), at the
+    reference UI's 1 spp: the counter ring wraps, the two staging slots alternate 2500 times each, and
+    the accumulator weight runs down to 1/5001."""
+    scene = scenes["spheres"]
+    width, height, frames = 64, 36, 5000
+    orc = O.OracleRenderer(scene, width, height)
+    orc.set_samples_per_pixel(1)
+    orc.render_frames(frames)
+    ctx = capi.Context(width, height)
+    ctx.set_scene(S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles))
+    u = S.pack_uniforms(scene.camera, 1, width, height, 1)
+    for f in range(1, frames + 1):
+        u[12] = f
+        ctx.set_uniforms(u)
+        ctx.render_frame()
+    assert np.array_equal(ctx.read_primary_ids(), orc.ids)
+    assert _f16_equal(ctx.read_frame_f16(), orc.frame_f16)
+    assert np.array_equal(ctx.read_accum(), orc.accum_rgb())
+    assert int(ctx.read_counters()[0]) == int(orc.counters[0])
+    ctx.close()
