@@ -113,6 +113,18 @@ int rt_set_uniforms(rt_context *ctx, const void *uniforms80);
  * default 6. */
 int rt_set_max_bounces(rt_context *ctx, uint32_t max_bounces);
 
+/*
+ * Opt-in extension, off by default because it changes the image: sample the
+ * emissive spheres as well as the emissive triangles at every bounce.  The
+ * reference's shader carries the sampling function
+ * (public/raytracer_compute.wgsl:109-171) and a TODO where it should be called
+ * (:226) but never calls it; with this switch it is called right after the
+ * triangle-light block (:211-225) and used the same way (one more shadow ray,
+ * same MIS weight).  Frames rendered with it go through the
+ * one-thread-per-pixel kernel (RT_MODE_BVH behaves as RT_MODE_BVH_TILES).
+ */
+int rt_set_sphere_lights(rt_context *ctx, int enable);
+
 /* Select the traversal (default RT_MODE_BVH).  All modes produce identical output. */
 int rt_set_mode(rt_context *ctx, int mode);
 

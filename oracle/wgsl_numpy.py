@@ -222,6 +222,32 @@ def sample_light_triangles(sc, hit_point, rng):  # raytracer_compute.wgsl:42-107
     return nd, (sel[16:19] * sel[19]).astype(np.float32), distance, pdf
 
 
+def sample_light_spheres(sc, hit_point, rng):  # raytracer_compute.wgsl:109-171 (defined in the shader, never called there)
+    zero = (vec3(0, 0, 0), vec3(0, 0, 0), f32(0), f32(0))
+    lights = [s for s in sc.spheres if s[11] > 0]
+    if not lights:
+        return zero
+    index = int(f32(rng.rand_f() * f32(len(lights))))        # u32(rand * count); count itself when rand_f exceeds 1
+    sel = lights[index] if index < len(lights) else np.zeros(16, dtype=np.float32)   # zero-initialised var
+    to_center = sel[0:3] - hit_point
+    dist = length(to_center)
+    if dist <= sel[3]:
+        return zero
+    with np.errstate(divide="ignore", invalid="ignore"):
+        cdir = (to_center / dist).astype(np.float32)
+        up = vec3(1, 0, 0) if abs(cdir[1]) > f32(0.99) else vec3(0, 1, 0)
+        right = normalize(cross(up, cdir))
+        forward = cross(cdir, right)
+        cos_max = f32(np.sqrt(f32(f32(1.0) - f32(f32(sel[3] * sel[3]) / f32(dist * dist)))))
+        cos_t = f32(f32(1.0) - f32(rng.rand_f() * f32(f32(1.0) - cos_max)))
+        sin_t = f32(np.sqrt(f32(f32(1.0) - f32(cos_t * cos_t))))
+        phi = f32(f32(f32(2.0) * PI) * rng.rand_f())
+        sphi, cphi = sincos(phi)
+        direction = normalize(((cdir * cos_t) + (right * f32(sin_t * cphi))) + (forward * f32(sin_t * sphi)))
+        pdf = f32(f32(1.0) / f32(f32(f32(f32(2.0) * PI) * f32(f32(1.0) - cos_max)) * f32(len(lights))))
+    return direction, (sel[8:11] * sel[11]).astype(np.float32), f32(dist - sel[3]), pdf
+
+
 def sample_cosine_hemisphere(normal, rng):  # common.wgsl:107-134
     r1 = rng.rand_f()
     r2 = rng.rand_f()
@@ -251,7 +277,7 @@ def brdf_pdf(n, d):  # raytracer_compute.wgsl:181-187
     return f32(c / PI)
 
 
-def ray_trace(sc, ro, rd, max_bounces, rng):  # raytracer_compute.wgsl:189-278
+def ray_trace(sc, ro, rd, max_bounces, rng, sphere_lights=False):  # raytracer_compute.wgsl:189-278
     sky = (vec3(1, 1, 1) * f32(0.4)).astype(np.float32)
     color = vec3(1, 1, 1)
     light = vec3(0, 0, 0)
@@ -274,6 +300,17 @@ def ray_trace(sc, ro, rd, max_bounces, rng):  # raytracer_compute.wgsl:189-278
                     mis = power_heuristic(lpdf, brdf_pdf(hit.normal, ldir))
                     brdf = f32(cos_theta / PI)
                     light = light + (((lem * brdf) * color) * mis) / lpdf
+        if sphere_lights:   # extension: the sampling the shader's TODO at :226 asks for, wired like the block above
+            sdir, sem, sdist, spdf = sample_light_spheres(sc, hit_point, rng)
+            if spdf > 0:
+                cos_theta = dot(hit.normal, sdir)
+                if cos_theta > 0:
+                    sh = ray_all(sc, hit_point + hit.normal * f32(0.01), sdir)
+                    if sh.t < 0 or sh.t > f32(sdist - f32(0.1)):
+                        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+                            mis = power_heuristic(spdf, brdf_pdf(hit.normal, sdir))
+                            brdf = f32(cos_theta / PI)
+                            light = light + (((sem * brdf) * color) * mis) / spdf
         emissive = f32(f32(hit.emission[0] + hit.emission[1]) + hit.emission[2]) > f32(0.01)
         if (i == 0 and emissive) or spec_bounce:
             incoming = -normalize(rd)
@@ -311,7 +348,7 @@ def f16_round_trip(x):
         return np.asarray(x, dtype=np.float32).astype(np.float16)
 
 
-def render_frame(uniforms, spheres, tris, accum, max_bounces=6):
+def render_frame(uniforms, spheres, tris, accum, max_bounces=6, sphere_lights=False):
     """raytracer_compute.wgsl:280-341 + accumulator.wgsl:44-68 over the whole image.
     uniforms: 20 float32; accum: (3, H, W) float32 in/out.  Returns (frame_f16 (H,W,4) uint16,
     ids (H,W) int32, rays)."""
@@ -346,7 +383,7 @@ def render_frame(uniforms, spheres, tris, accum, max_bounces=6):
             total = vec3(0, 0, 0)
             pid = -1
             for s in range(int(spp_f)):
-                light, fid = ray_trace(sc, cam_pos.copy(), rd, max_bounces, rng)
+                light, fid = ray_trace(sc, cam_pos.copy(), rd, max_bounces, rng, sphere_lights)
                 total = total + light
                 if s == 0:
                     pid = fid

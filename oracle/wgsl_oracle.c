@@ -292,6 +292,7 @@ static OrcHit ray_triangle(v3 ro, v3 rd, const TriV *tri) /* common.wgsl:170-211
 typedef struct {
     const unsigned char *spheres; uint32_t n_spheres;
     const unsigned char *tris; uint32_t n_tris;
+    int sphere_lights; /* ORC_SPHERE_LIGHTS: ray_trace also samples emissive spheres (an extension, see below) */
 } SceneV;
 
 static OrcHit ray_all(v3 ro, v3 rd, const SceneV *sc) /* raytracer_compute.wgsl:15-39 */
@@ -407,6 +408,60 @@ static LightSample sample_light_triangles(v3 hit_point, uint32_t *state, const S
     return out;
 }
 
+/*
+ * raytracer_compute.wgsl:109-171.  The shader defines this function and never calls it
+ * (its author's TODO at :226); ray_trace below calls it only with ORC_SPHERE_LIGHTS.
+ * `var selected_sphere: Sphere` is zero-initialised in WGSL, which is what remains when
+ * u32(rand * count) lands on count (rand_f can reach 1.0000005).
+ */
+static LightSample sample_light_spheres(v3 hit_point, uint32_t *state, const SceneV *sc)
+{
+    uint32_t light_count = 0u;
+    for (uint32_t i = 0; i < sc->n_spheres; i++) {
+        SphereV sp = load_sphere(sc->spheres + 64u * (size_t)i);
+        if (sp.emissionStrength > 0.0f) light_count++;
+    }
+    if (light_count == 0u) return zero_light_sample();
+
+    uint32_t random_sphere_index = (uint32_t)(orc_rand_f(state) * (float)light_count);
+    uint32_t current_index = 0u;
+    SphereV selected;
+    memset(&selected, 0, sizeof selected);
+    for (uint32_t i = 0; i < sc->n_spheres; i++) {
+        SphereV sp = load_sphere(sc->spheres + 64u * (size_t)i);
+        if (sp.emissionStrength > 0.0f) {
+            if (current_index == random_sphere_index) { selected = sp; break; }
+            current_index++;
+        }
+    }
+
+    v3 to_center = vsub(selected.center, hit_point);
+    float distance_to_center = vlength(to_center);
+    if (distance_to_center <= selected.radius) return zero_light_sample();
+
+    v3 center_direction = vdivs(to_center, distance_to_center);
+    v3 up = fabsf(center_direction.y) > 0.99f ? V(1.0f, 0.0f, 0.0f) : V(0.0f, 1.0f, 0.0f);
+    v3 right = vnormalize(vcross(up, center_direction));
+    v3 forward = vcross(center_direction, right);
+
+    float cos_theta_max = sqrtf(1.0f - (selected.radius * selected.radius) / (distance_to_center * distance_to_center));
+    float cos_theta = 1.0f - orc_rand_f(state) * (1.0f - cos_theta_max);
+    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    float phi = 2.0f * ORC_PI * orc_rand_f(state);
+    float sphi, cphi;
+    orc_sincosf(phi, &sphi, &cphi);
+
+    v3 sample_direction = vnormalize(vadd(vadd(vscale(center_direction, cos_theta), vscale(right, sin_theta * cphi)),
+                                          vscale(forward, sin_theta * sphi)));
+
+    LightSample out;
+    out.direction = sample_direction;
+    out.emission = vscale(selected.emissionColor, selected.emissionStrength);
+    out.distance = distance_to_center - selected.radius;
+    out.pdf = 1.0f / (2.0f * ORC_PI * (1.0f - cos_theta_max) * (float)light_count);
+    return out;
+}
+
 static v3 sample_cosine_hemisphere(v3 normal, uint32_t *state) /* common.wgsl:107-134 */
 {
     float r1 = orc_rand_f(state);
@@ -482,6 +537,30 @@ static v3 ray_trace(v3 ro, v3 rd, uint32_t maxBounceCount, uint32_t *state,
                     c = vscale(c, mis_weight);
                     c = vdivs(c, ts.pdf);
                     light = vadd(light, c);
+                }
+            }
+        }
+
+        /* Extension, off unless ORC_SPHERE_LIGHTS: the sphere-light sampling the shader's TODO at
+         * raytracer_compute.wgsl:226 asks for, wired exactly like the triangle block above. */
+        if (sc->sphere_lights) {
+            LightSample ss = sample_light_spheres(hit_point, state, sc);
+            if (ss.pdf > 0.0f) {
+                float cos_theta = vdot(hit_normal, ss.direction);
+                if (cos_theta > 0.0f) {
+                    v3 so = vadd(hit_point, vscale(hit_normal, 0.01f));
+                    OrcHit shadow_hit = ray_all(so, ss.direction, sc);
+                    (*n_rays)++;
+                    if (shadow_hit.t < 0.0f || shadow_hit.t > ss.distance - 0.1f) {
+                        float brdf_pdf_val = brdf_pdf(hit_normal, ss.direction);
+                        float mis_weight = power_heuristic(ss.pdf, brdf_pdf_val);
+                        float brdf = cos_theta / ORC_PI;
+                        v3 c = vscale(ss.emission, brdf);
+                        c = vmul(c, color);
+                        c = vscale(c, mis_weight);
+                        c = vdivs(c, ss.pdf);
+                        light = vadd(light, c);
+                    }
                 }
             }
         }
@@ -642,6 +721,18 @@ int orc_render_frame(const void *uniforms80,
                      float *accum, uint16_t *frame_f16, int32_t *ids,
                      uint64_t *counters, int n_threads)
 {
+    return orc_render_frame_ex(uniforms80, spheres, n_spheres, tris, n_tris, max_bounces, x0, y0, x1, y1, accum,
+                               frame_f16, ids, counters, n_threads, 0u);
+}
+
+int orc_render_frame_ex(const void *uniforms80,
+                        const void *spheres, uint32_t n_spheres,
+                        const void *tris, uint32_t n_tris,
+                        uint32_t max_bounces,
+                        int x0, int y0, int x1, int y1,
+                        float *accum, uint16_t *frame_f16, int32_t *ids,
+                        uint64_t *counters, int n_threads, uint32_t flags)
+{
     if (!uniforms80 || !accum) return -1;
     FrameJob j;
     memset(&j, 0, sizeof j);
@@ -652,6 +743,7 @@ int orc_render_frame(const void *uniforms80,
     if (x0 < 0 || y0 < 0 || x1 > j.W || y1 > j.H || x0 > x1 || y0 > y1) return -3;
     j.sc.spheres = (const unsigned char *)spheres; j.sc.n_spheres = n_spheres;
     j.sc.tris = (const unsigned char *)tris; j.sc.n_tris = n_tris;
+    j.sc.sphere_lights = (flags & ORC_SPHERE_LIGHTS) != 0u;
     j.max_bounces = max_bounces;
     j.x0 = x0; j.y0 = y0; j.x1 = x1; j.y1 = y1;
     j.accum = accum; j.frame_f16 = frame_f16; j.ids = ids;
@@ -690,7 +782,7 @@ void orc_ray_all(const float origin[3], const float dir[3],
                  const void *spheres, uint32_t n_spheres,
                  const void *tris, uint32_t n_tris, OrcHit *out)
 {
-    SceneV sc = {(const unsigned char *)spheres, n_spheres, (const unsigned char *)tris, n_tris};
+    SceneV sc = {(const unsigned char *)spheres, n_spheres, (const unsigned char *)tris, n_tris, 0};
     *out = ray_all(ld3(origin), ld3(dir), &sc);
 }
 
@@ -699,7 +791,7 @@ float orc_sample_light_triangles(const float hit_point[3], uint32_t *state,
                                  float out_dir[3], float out_emission[3],
                                  float *out_distance)
 {
-    SceneV sc = {NULL, 0, (const unsigned char *)tris, n_tris};
+    SceneV sc = {NULL, 0, (const unsigned char *)tris, n_tris, 0};
     LightSample s = sample_light_triangles(ld3(hit_point), state, &sc);
     st3(out_dir, s.direction);
     st3(out_emission, s.emission);
@@ -727,7 +819,7 @@ void orc_ray_trace(const float origin[3], const float dir[3], uint32_t max_bounc
                    const void *tris, uint32_t n_tris, float out_light[3],
                    uint64_t *n_rays, int32_t *first_id)
 {
-    SceneV sc = {(const unsigned char *)spheres, n_spheres, (const unsigned char *)tris, n_tris};
+    SceneV sc = {(const unsigned char *)spheres, n_spheres, (const unsigned char *)tris, n_tris, 0};
     uint64_t local = 0;
     int32_t fid = -1;
     st3(out_light, ray_trace(ld3(origin), ld3(dir), max_bounces, state, &sc, &local, &fid));

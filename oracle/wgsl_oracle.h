@@ -115,6 +115,22 @@ int orc_render_frame(const void *uniforms80,
                      float *accum, uint16_t *frame_f16, int32_t *ids,
                      uint64_t *counters, int n_threads);
 
+/*
+ * orc_render_frame with options.  ORC_SPHERE_LIGHTS: every bounce also samples the emissive
+ * spheres with sample_light_spheres (raytracer_compute.wgsl:109-171, defined there and
+ * never called) through a second shadow ray, wired like the triangle-light block at
+ * :211-225.  The reference does not do this (its TODO at :226); it is an extension that
+ * renderer and oracle share, off by default.
+ */
+#define ORC_SPHERE_LIGHTS 1u
+int orc_render_frame_ex(const void *uniforms80,
+                        const void *spheres, uint32_t n_spheres,
+                        const void *tris, uint32_t n_tris,
+                        uint32_t max_bounces,
+                        int x0, int y0, int x1, int y1,
+                        float *accum, uint16_t *frame_f16, int32_t *ids,
+                        uint64_t *counters, int n_threads, uint32_t flags);
+
 #ifdef __cplusplus
 }
 #endif

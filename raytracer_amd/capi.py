@@ -31,6 +31,7 @@ SYMBOLS = {
     "rt_set_uniforms": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_set_max_bounces": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rt_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_set_sphere_lights": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_set_counting": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rt_render_frame": (C.c_int, [C.c_void_p]),
@@ -223,6 +224,9 @@ class Context:
         v = C.c_uint32()
         _check(self.lib.rt_frames_per_launch(self.handle, C.byref(v)))
         return v.value
+
+    def set_sphere_lights(self, enable: bool):
+        _check(self.lib.rt_set_sphere_lights(self.handle, 1 if enable else 0))
 
     def scene_stats(self) -> dict:
         out = np.zeros(4, dtype=np.uint64)

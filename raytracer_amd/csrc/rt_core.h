@@ -161,6 +161,7 @@ struct FrameParams {
     uint32_t res_x_u;  // u32(uniforms.resolution.x)
     uint32_t max_bounces;
     int32_t width, height;
+    uint32_t sphere_lights; // opt-in extension: every bounce also samples the emissive spheres (see rt_pixel.h)
 };
 
 struct Hit { // common.wgsl:50-57
@@ -474,6 +475,52 @@ RT_HD LightSample sample_light_triangles(const SceneView &sc, f3 hit_point, uint
     out.direction = normalized_direction;
     out.emission = xyz(l4);
     out.distance = distance;
+    return out;
+}
+
+// raytracer_compute.wgsl:109-171: defined in the shader and never called there; used by the
+// opt-in sphere-light extension (FrameParams::sphere_lights).  The all-zero sphere stands for
+// WGSL's zero-initialised `selected_sphere` when u32(rand * count) lands on count.
+RT_HD LightSample sample_light_spheres(const SceneView &sc, f3 hit_point, uint32_t &state)
+{
+    LightSample out;
+    out.direction = mk3(0, 0, 0); out.emission = mk3(0, 0, 0); out.distance = 0.0f; out.pdf = 0.0f;
+    uint32_t light_count = 0u;
+    for (uint32_t i = 0; i < sc.n_spheres; i++)
+        if (sc.spheres[4 * i + 2].w > 0.0f) light_count++;
+    if (light_count == 0u) return out;
+
+    uint32_t random_sphere_index = (uint32_t)(rand_f(state) * (float)light_count);
+    uint32_t current_index = 0u;
+    f4 s0 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    for (uint32_t i = 0; i < sc.n_spheres; i++) {
+        if (sc.spheres[4 * i + 2].w > 0.0f) {
+            if (current_index == random_sphere_index) { s0 = sc.spheres[4 * i]; s2 = sc.spheres[4 * i + 2]; break; }
+            current_index++;
+        }
+    }
+    f3 to_center = sub(xyz(s0), hit_point);
+    float distance_to_center = length(to_center);
+    float radius = s0.w;
+    if (distance_to_center <= radius) return out;
+
+    f3 center_direction = divs(to_center, distance_to_center);
+    bool steep = fabsf(center_direction.y) > 0.99f;
+    f3 up = mk3(steep ? 1.0f : 0.0f, steep ? 0.0f : 1.0f, 0.0f);
+    f3 right = normalize(cross(up, center_direction));
+    f3 forward = cross(center_direction, right);
+
+    float cos_theta_max = sqrtf(1.0f - (radius * radius) / (distance_to_center * distance_to_center));
+    float cos_theta = 1.0f - rand_f(state) * (1.0f - cos_theta_max);
+    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    float phi = 2.0f * kPi * rand_f(state);
+    float sphi, cphi;
+    sincos_f(phi, sphi, cphi);
+    out.direction = normalize(add(add(scale(center_direction, cos_theta), scale(right, sin_theta * cphi)),
+                                  scale(forward, sin_theta * sphi)));
+    out.pdf = 1.0f / (2.0f * kPi * (1.0f - cos_theta_max) * (float)light_count);
+    out.emission = scale(xyz(s2), s2.w);
+    out.distance = distance_to_center - radius;
     return out;
 }
 

@@ -577,6 +577,7 @@ struct rt_context {
     int next_slot = 0;
     int tune_overlap = 1;
     int tune_shade_wait = 12;
+    bool sphere_lights = false; // opt-in extension: emissive spheres are sampled too (one-thread-per-pixel kernel)
     int tune_shade_num = 2, tune_leaf_lanes = 12, tune_blocks_per_cu = 0, tune_batch = 0, tune_sdone_lanes = 2, tune_refill_lanes = 0, tune_max_leaf = 4, tune_tri_cost_x10 = 12, tune_lds_state = RT_LDS_PARK;
 
     void free_scene()
@@ -922,6 +923,13 @@ int rt_set_max_bounces(rt_context *c, uint32_t max_bounces)
     return RT_OK;
 }
 
+int rt_set_sphere_lights(rt_context *c, int enable)
+{
+    if (!c) return fail(RT_ERR_INVALID, "null context");
+    c->sphere_lights = enable != 0;
+    return RT_OK;
+}
+
 int rt_set_mode(rt_context *c, int mode)
 {
     if (!c) return fail(RT_ERR_INVALID, "null context");
@@ -959,7 +967,7 @@ static int render_frames_impl(rt_context *c, uint32_t first_frame_index, uint32_
         return fail(RT_ERR_INVALID, "frame index beyond 2^24 is not exact in the f32 uniform");
     RT_HIP_CHECK(hipSetDevice(c->device));
     RT_HIP_CHECK(hipEventRecord(c->ev_start, c->stream));
-    if (c->mode == RT_MODE_BVH) {
+    if (c->mode == RT_MODE_BVH && !c->sphere_lights) {
         if ((rc = launch_persistent(c, first_frame_index, n_frames, stride, sum))) return rc;
     } else {
         for (uint32_t k = 0; k < n_frames; k++) {
@@ -967,6 +975,7 @@ static int render_frames_impl(rt_context *c, uint32_t first_frame_index, uint32_
             rt::FrameParams fp;
             std::string err;
             if (!rt::make_frame_params(c->uniforms, c->max_bounces, fp, err)) return fail(RT_ERR_INVALID, err);
+            fp.sphere_lights = c->sphere_lights ? 1u : 0u;
             if ((rc = launch_tiles(c, fp, sum))) return rc;
         }
     }

@@ -10,8 +10,8 @@ namespace rt {
 
 // raytracer_compute.wgsl:189-278.  BRUTE selects the reference's own ray_all.
 template <bool BRUTE, class Stack>
-RT_HD f3 ray_trace(const SceneView &sc, f3 ro, f3 rd, uint32_t max_bounces, uint32_t &state, Stack &stack,
-                   uint32_t &n_rays, int32_t &first_id, TestCounts *cnt)
+RT_HD f3 ray_trace(const SceneView &sc, f3 ro, f3 rd, uint32_t max_bounces, bool sphere_lights, uint32_t &state,
+                   Stack &stack, uint32_t &n_rays, int32_t &first_id, TestCounts *cnt)
 {
     f3 sky_color = scale(mk3(1.0f, 1.0f, 1.0f), 0.4f);
     f3 color = mk3(1.0f, 1.0f, 1.0f);
@@ -49,6 +49,29 @@ RT_HD f3 ray_trace(const SceneView &sc, f3 ro, f3 rd, uint32_t max_bounces, uint
                 if (reached) light = add(light, nee_contribution(ts, hit.normal, cos_theta, color));
             }
         }
+        // Extension (off by default): the sphere-light sampling that the shader's TODO at
+        // raytracer_compute.wgsl:226 asks for, with sample_light_spheres (:109-171) wired exactly
+        // like the triangle-light block above: a second sample, a second shadow ray.
+        if (sphere_lights) {
+            LightSample ss = sample_light_spheres(sc, hit_point, state);
+            if (ss.pdf > 0.0f) {
+                float cos_theta = dot(hit.normal, ss.direction);
+                if (cos_theta > 0.0f) {
+                    f3 so = add(hit_point, scale(hit.normal, 0.01f));
+                    float limit = ss.distance - 0.1f;
+                    bool reached;
+                    if (BRUTE) {
+                        float st;
+                        (void)brute_closest(sc, so, ss.direction, st);
+                        reached = st < 0.0f || st > limit;
+                    } else {
+                        reached = !trace_occluded(sc, so, ss.direction, limit, stack, cnt);
+                    }
+                    n_rays++;
+                    if (reached) light = add(light, nee_contribution(ss, hit.normal, cos_theta, color));
+                }
+            }
+        }
         f3 em;
         bool has_em;
         bool alive = finish_bounce(hit, i, ro, rd, color, em, has_em, is_specular_bounce, state);
@@ -70,7 +93,7 @@ RT_HD f3 render_pixel(const SceneView &sc, const FrameParams &fp, int px, int py
     primary_id = -1;
     for (uint32_t s = 0; s < fp.spp; s++) {
         int32_t fid = -1;
-        total = add(total, ray_trace<BRUTE>(sc, fp.cam_pos, rd, fp.max_bounces, state, stack, n_rays, fid, cnt));
+        total = add(total, ray_trace<BRUTE>(sc, fp.cam_pos, rd, fp.max_bounces, fp.sphere_lights != 0u, state, stack, n_rays, fid, cnt));
         if (s == 0u) primary_id = fid;
     }
     return divs(total, fp.spp_f);

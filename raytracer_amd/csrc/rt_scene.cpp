@@ -427,6 +427,7 @@ bool make_frame_params(const void *uniforms80, uint32_t max_bounces, FrameParams
     fp.seed_add = (uint32_t)frameIndex * 12345u;
     fp.res_x_u = (uint32_t)res_x;
     fp.max_bounces = max_bounces;
+    fp.sphere_lights = 0u;
     fp.width = (int32_t)res_x;
     fp.height = (int32_t)res_y;
     return true;

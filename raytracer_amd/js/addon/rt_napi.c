@@ -190,6 +190,7 @@ static napi_value js_set_uniforms(napi_env env, napi_callback_info info)
 INT_SETTER(js_set_max_bounces, rt_set_max_bounces(ctx, (uint32_t)v))
 INT_SETTER(js_set_mode, rt_set_mode(ctx, v))
 INT_SETTER(js_set_counting, rt_set_counting(ctx, v))
+INT_SETTER(js_set_sphere_lights, rt_set_sphere_lights(ctx, v))
 
 static napi_value js_set_tuning(napi_env env, napi_callback_info info)
 {
@@ -326,6 +327,7 @@ static napi_value init(napi_env env, napi_value exports)
         {"deviceCount", js_device_count}, {"create", js_create}, {"destroy", js_destroy},
         {"setScene", js_set_scene}, {"setUniforms", js_set_uniforms}, {"setMaxBounces", js_set_max_bounces},
         {"setMode", js_set_mode}, {"setCounting", js_set_counting}, {"setTuning", js_set_tuning},
+        {"setSphereLights", js_set_sphere_lights},
         {"renderFrame", js_render_frame}, {"renderFrames", js_render_frames}, {"sync", js_sync},
         {"lastRenderMs", js_last_render_ms}, {"readAccum", js_read_accum}, {"readFrameF16", js_read_frame_f16},
         {"readPrimaryIds", js_read_primary_ids}, {"readCounters", js_read_counters},

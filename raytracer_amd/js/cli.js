@@ -7,7 +7,7 @@
  *
  *   node cli.js --scene scene.json --width 640 --height 360 --spp 16 --frames 4
  *               [--bounces 6] [--image out.png | --ppm out.ppm] [--preview-every k]
- *               [--apply-model-transforms] [--dump prefix] [--per-frame]
+ *               [--apply-model-transforms] [--sphere-lights] [--dump prefix] [--per-frame]
  *
  * --preview-every k rewrites the image file after every k frames (progressive preview).
  */
@@ -21,6 +21,7 @@ function parseArgs(argv) {
         const k = argv[i];
         if (k === '--per-frame') { a.perFrame = true; continue; }
         if (k === '--apply-model-transforms') { a.applyModelTransforms = true; continue; }
+        if (k === '--sphere-lights') { a.sphereLights = true; continue; }
         const v = argv[++i];
         if (k === '--scene') a.scene = v;
         else if (k === '--width') a.width = parseInt(v, 10);
@@ -42,7 +43,8 @@ async function main() {
     const canvas = { width: a.width, height: a.height, pixels: a.ppm ? new Uint8Array(a.width * a.height * 4) : null };
     // the canvas image is only needed when a file is written: fill it on demand, not on every frame
     const renderer = await HipRenderer.Create(canvas, a.scene, { maxBounces: a.bounces, presentEvery: 1 << 30,
-                                                                 applyModelTransforms: a.applyModelTransforms });
+                                                                 applyModelTransforms: a.applyModelTransforms,
+                                                                 sphereLights: a.sphereLights });
     if (!renderer) process.exit(1);
     renderer.setSamplesPerPixel(a.spp);
     const t0 = process.hrtime.bigint();

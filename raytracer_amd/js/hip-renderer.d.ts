@@ -18,6 +18,10 @@ export interface HipRendererOptions {
     stripeCount?: number;
     /** Fill canvas.pixels on every k-th frame only (default 1). */
     presentEvery?: number;
+    /** Apply a model's scale / rotation / position (the reference ignores them). Off by default. */
+    applyModelTransforms?: boolean;
+    /** Sample emissive spheres as well as emissive triangles at every bounce. Off by default. */
+    sphereLights?: boolean;
 }
 
 export class HipRenderer {

@@ -41,7 +41,8 @@ class HipRenderer {
     }
 
     // src/webgpu-renderer.ts:48-103.  options: { device, maxBounces, stripeRows, stripeIndex, stripeCount,
-    // presentEvery, applyModelTransforms }: applyModelTransforms applies a model's scale / rotation / position, which the
+    // presentEvery, applyModelTransforms, sphereLights }: sphereLights samples emissive spheres too (the shader's
+    // unused sample_light_spheres; off by default, changes the image); applyModelTransforms applies a model's scale / rotation / position, which the
     // reference reads and ignores (off by default); presentEvery = k copies the image into canvas.pixels on every k-th frame only (default 1,
     // every frame as the reference's canvas pass does; the copy reads the accumulator back and so waits for the GPU)
     static async Create(canvas, scenePath, options) {
@@ -56,6 +57,7 @@ class HipRenderer {
                     opt.stripeRows || 8, opt.stripeIndex || 0, opt.stripeCount || 1);
                 if (opt.maxBounces !== undefined) renderer.native.setMaxBounces(renderer.handle, opt.maxBounces);
                 renderer.presentEvery = Math.max(1, opt.presentEvery | 0);
+                if (opt.sphereLights) renderer.native.setSphereLights(renderer.handle, 1);
             } catch (error) {
                 throw new RethrownError('Failed to create pipelines', error);
             }

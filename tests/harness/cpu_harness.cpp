@@ -23,6 +23,10 @@ struct HostStack {
 };
 } // namespace
 
+static int g_sphere_lights = 0;
+// the opt-in sphere-light extension for the following har_render_frame calls
+extern "C" void har_set_sphere_lights(int enable) { g_sphere_lights = enable; }
+
 extern "C" int har_render_frame(const void *uniforms80, const void *spheres, uint32_t n_spheres,
                                 const void *tris, uint32_t n_tris, uint32_t max_bounces, int brute,
                                 uint32_t max_leaf, float *accum, uint16_t *frame_f16, int32_t *ids,
@@ -35,6 +39,7 @@ extern "C" int har_render_frame(const void *uniforms80, const void *spheres, uin
     rt::FrameParams fp;
     std::string err;
     if (!rt::make_frame_params(uniforms80, max_bounces, fp, err)) return -1;
+    fp.sphere_lights = g_sphere_lights ? 1u : 0u;
     rt::SceneView sc;
     sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data();
     sc.tri_raw = bs.tri_raw.data(); sc.spheres = bs.spheres.data(); sc.lights = bs.lights.data();

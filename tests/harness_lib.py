@@ -28,11 +28,12 @@ def _p(a):
 
 
 class HarnessRenderer:
-    def __init__(self, scene, width, height, brute=False, max_bounces=6, max_leaf=0):
+    def __init__(self, scene, width, height, brute=False, max_bounces=6, max_leaf=0, sphere_lights=False):
         from raytracer_amd import scene as S
 
         self.S, self.scene, self.width, self.height = S, scene, width, height
         self.brute, self.max_bounces, self.max_leaf = brute, max_bounces, max_leaf
+        self.sphere_lights = sphere_lights
         if isinstance(scene, tuple):  # (camera, packed spheres, packed triangles)
             self.scene = S.Scene(camera=scene[0])
             self.spheres, self.tris = scene[1], scene[2]
@@ -48,6 +49,7 @@ class HarnessRenderer:
     def render(self, spp):
         self.frame_index += 1
         u = self.S.pack_uniforms(self.scene.camera, self.frame_index, self.width, self.height, spp)
+        self.L.har_set_sphere_lights(1 if self.sphere_lights else 0)
         rc = self.L.har_render_frame(_p(u), _p(self.spheres), len(self.spheres), _p(self.tris), len(self.tris),
                                      self.max_bounces, 1 if self.brute else 0, self.max_leaf, _p(self.accum),
                                      _p(self.frame_f16), _p(self.ids), _p(self.counters), os.cpu_count() or 1)

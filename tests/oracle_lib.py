@@ -74,6 +74,8 @@ def lib():
                                    C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.orc_render_frame.restype = C.c_int
+    L.orc_render_frame_ex.argtypes = L.orc_render_frame.argtypes + [C.c_uint32]
+    L.orc_render_frame_ex.restype = C.c_int
     _lib = L
     return L
 
@@ -167,13 +169,14 @@ class OracleRenderer:
     frame; the accumulator planes persist; reset only zeroes frameIndex."""
 
     def __init__(self, scene, width: int, height: int, max_bounces: int = 6, threads: int = 0,
-                 rect=None):
+                 rect=None, sphere_lights: bool = False):
         from raytracer_amd import scene as S
 
         self._S = S
         self.scene = scene
         self.width, self.height = width, height
         self.max_bounces = max_bounces
+        self.sphere_lights = sphere_lights   # ORC_SPHERE_LIGHTS extension
         self.threads = threads or (os.cpu_count() or 1)
         if isinstance(scene, tuple):  # (camera, packed spheres, packed triangles)
             self.scene = S.Scene(camera=scene[0])
@@ -200,9 +203,9 @@ class OracleRenderer:
         u = self._S.pack_uniforms(self.scene.camera, self.frame_index, self.width, self.height,
                                   self.samples_per_pixel)
         x0, y0, x1, y1 = self.rect
-        rc = lib().orc_render_frame(_ptr(u), _ptr(self.spheres), len(self.spheres), _ptr(self.tris), len(self.tris),
-                                    self.max_bounces, x0, y0, x1, y1, _ptr(self.accum), _ptr(self.frame_f16),
-                                    _ptr(self.ids), _ptr(self.counters), self.threads)
+        rc = lib().orc_render_frame_ex(_ptr(u), _ptr(self.spheres), len(self.spheres), _ptr(self.tris), len(self.tris),
+                                       self.max_bounces, x0, y0, x1, y1, _ptr(self.accum), _ptr(self.frame_f16),
+                                       _ptr(self.ids), _ptr(self.counters), self.threads, 1 if self.sphere_lights else 0)
         if rc != 0:
             raise RuntimeError("orc_render_frame failed: %d" % rc)
 

@@ -125,3 +125,32 @@ def test_card_deck_needs_more_than_sixteen_stack_entries():
     assert np.array_equal(har.ids, orc.ids)
     assert np.array_equal(har.accum, orc.accum)
     assert int(har.counters[7]) > 16 and len(scene.triangles) > 4096
+
+
+@pytest.mark.parametrize("brute", [True, False])
+def test_sphere_light_extension_matches_oracle(brute):
+    """The opt-in sampling of emissive spheres (the shader's own sample_light_spheres, which it never
+    calls): shared core against the oracle, on scenes with one and with no emissive sphere."""
+    from tests.synth import edge_scenes
+
+    for name in ("emissive_and_mirror_spheres", "many_spheres", "no_lights"):
+        scene = edge_scenes()[name]
+        orc = O.OracleRenderer(scene, 64, 36, sphere_lights=True)
+        orc.set_samples_per_pixel(3)
+        har = HarnessRenderer(scene, 64, 36, brute=brute, sphere_lights=True)
+        for _ in range(2):
+            orc.render()
+            har.render(3)
+        assert np.array_equal(har.ids, orc.ids)
+        assert np.array_equal(har.frame_f16, orc.frame_f16)
+        assert np.array_equal(har.accum, orc.accum)
+        assert int(har.counters[0]) == int(orc.counters[0])
+    # and it does change the image where there is an emissive sphere
+    scene = edge_scenes()["emissive_and_mirror_spheres"]
+    off = O.OracleRenderer(scene, 64, 36)
+    off.set_samples_per_pixel(3)
+    off.render()
+    on = O.OracleRenderer(scene, 64, 36, sphere_lights=True)
+    on.set_samples_per_pixel(3)
+    on.render()
+    assert not np.array_equal(on.accum, off.accum) and int(on.counters[0]) > int(off.counters[0])

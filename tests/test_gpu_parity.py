@@ -404,3 +404,29 @@ def test_five_thousand_single_frames(scenes):
     assert np.array_equal(ctx.read_accum(), orc.accum_rgb())
     assert int(ctx.read_counters()[0]) == int(orc.counters[0])
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", [capi.RT_MODE_BVH, capi.RT_MODE_BRUTE_FORCE])
+def test_sphere_light_extension(mode):
+    """rt_set_sphere_lights: emissive spheres sampled at every bounce (the shader's unused
+    sample_light_spheres), bit-exact against the oracle built with the same option."""
+    from tests.synth import edge_scenes
+
+    for name in ("emissive_and_mirror_spheres", "many_spheres", "no_lights"):
+        scene = edge_scenes()[name]
+        width, height, spp = 96, 54, 3
+        orc = O.OracleRenderer(scene, width, height, sphere_lights=True)
+        orc.set_samples_per_pixel(spp)
+        ctx = capi.Context(width, height)
+        ctx.set_mode(mode)
+        ctx.set_sphere_lights(True)
+        ctx.set_scene(S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles))
+        orc.render_frames(3)
+        ctx.set_uniforms(S.pack_uniforms(scene.camera, 1, width, height, spp))
+        ctx.render_frame()
+        ctx.render_frames(2, 2)
+        assert np.array_equal(ctx.read_primary_ids(), orc.ids)
+        assert _f16_equal(ctx.read_frame_f16(), orc.frame_f16)
+        assert np.array_equal(ctx.read_accum(), orc.accum_rgb())
+        assert int(ctx.read_counters()[0]) == int(orc.counters[0])
+        ctx.close()

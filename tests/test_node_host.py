@@ -107,7 +107,7 @@ console.log(JSON.stringify({n: t.length, second: t[1], bad: bad.length, badv0: b
 def test_addon_exports_the_abi():
     script = "const a = require('%s/rt_hip_napi.node'); console.log(JSON.stringify(Object.keys(a).sort()))" % JS
     names = json.loads(node(script))
-    for n in ["create", "destroy", "setScene", "setUniforms", "renderFrame", "renderFrames", "readAccum",
+    for n in ["setSphereLights", "create", "destroy", "setScene", "setUniforms", "renderFrame", "renderFrames", "readAccum",
               "readPrimaryIds", "readFrameF16", "takeTriangleTests", "readCounters", "deviceCount", "sync"]:
         assert n in names
 

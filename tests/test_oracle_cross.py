@@ -53,15 +53,24 @@ def test_edge_scene_frames_agree(name):
     _frames_agree(edge_scenes()[name], 16, 9, 1, 2)
 
 
-def _frames_agree(sc, width, height, frames, spp):
+@pytest.mark.parametrize("name", ["emissive_and_mirror_spheres", "many_spheres"])
+def test_sphere_light_extension_agrees(name):
+    """sample_light_spheres (raytracer_compute.wgsl:109-171) and its opt-in use, in both restatements."""
+    from tests.synth import edge_scenes
+
+    _frames_agree(edge_scenes()[name], 16, 9, 1, 2, sphere_lights=True)
+
+
+def _frames_agree(sc, width, height, frames, spp, sphere_lights=False):
     spheres, tris = S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles)
-    orc = O.OracleRenderer(sc, width, height)
+    orc = O.OracleRenderer(sc, width, height, sphere_lights=sphere_lights)
     orc.set_samples_per_pixel(spp)
     accum = np.zeros((3, height, width), np.float32)
     rays = 0
     for f in range(1, frames + 1):
         orc.render()
-        frame, ids, r = N.render_frame(S.pack_uniforms(sc.camera, f, width, height, spp), spheres, tris, accum)
+        frame, ids, r = N.render_frame(S.pack_uniforms(sc.camera, f, width, height, spp), spheres, tris, accum,
+                                       sphere_lights=sphere_lights)
         rays += r
         assert np.array_equal(ids, orc.ids)
         assert np.array_equal(frame, orc.frame_f16)
