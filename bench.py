@@ -249,7 +249,7 @@ def main():
     brute_flops_per_ray = F_SPH * len(spheres) + F_TRI * len(tris)
     frames = K * frames_per_step
     batch = frames_per_launch       # frames per kernel launch, as chosen by the library for this context
-    launches = (frames_this_rank + batch - 1) // batch
+    launches = max(1, (frames_this_rank + batch - 1) // batch)
     rays_per_launch = rays / world / launches
     launch_ms = kernel_ms / launches
     achieved = flops_per_ray * rays_per_launch / (launch_ms * 1e-3) / 1e12
@@ -268,7 +268,7 @@ def main():
         "n_gpus": world,
         "steps": K,
         "warmup": W,
-        "ms_per_step": dt * 1e3 / K,
+        "ms_per_step": dt * 1e3 / max(K, 1),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -282,7 +282,7 @@ def main():
                             ", rows dealt to %d GPUs in 8-row stripes + RCCL all-gather" % world)),
             "frames": K * frames_per_step,
             "spp_per_frame": SPP,
-            "ms_per_frame": dt * 1e3 / (K * frames_per_step),
+            "ms_per_frame": dt * 1e3 / max(K * frames_per_step, 1),
             "rays": rays,
             "ray_all_calls_of_the_reference": ray_calls,
             "note": "value counts rays actually traversed; the camera ray of a pixel is traversed once per frame and its "
