@@ -251,7 +251,7 @@ def main():
     batch = frames_per_launch       # frames per kernel launch, as chosen by the library for this context
     launches = max(1, (frames_this_rank + batch - 1) // batch)
     rays_per_launch = rays / world / launches
-    launch_ms = kernel_ms / launches
+    launch_ms = max(kernel_ms / launches, 1e-9)
     achieved = flops_per_ray * rays_per_launch / (launch_ms * 1e-3) / 1e12
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
