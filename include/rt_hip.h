@@ -58,11 +58,14 @@ typedef enum rt_tuning {
     RT_TUNE_TRI_COST_X10 = 7,  /* SAH cost of a triangle test relative to a node visit, in tenths; next rt_set_scene */
     RT_TUNE_LDS_STATE = 8,     /* where lanes keep rarely touched state: 2 = in LDS as far as it fits (default), 1 = scenes
                                   of <= 4096 triangles keep only shadow-ray state there, 0 = all of it in registers    */
-    RT_TUNE_SHADE_WAIT = 10,   /* shade finished lanes anyway once they have waited this many traversal turns
-                                  (default 12); 0 = never */
     RT_TUNE_OVERLAP_FRAMES = 9, /* single-frame renders: 1 = trace on alternating side streams so that consecutive
                                   frames overlap (default), 0 = trace and accumulate in one kernel on the context's stream */
-    RT_TUNE_END
+    RT_TUNE_SHADE_WAIT = 10,   /* shade finished lanes anyway once they have waited this many traversal turns
+                                  (default 12); 0 = never */
+    RT_TUNE_MAX_STACK = 11,    /* largest traversal-stack need (entries) the persistent kernel takes on, 1..64 (default
+                                  64, all its stack can hold); scenes whose tree needs more are rendered by the
+                                  one-thread-per-pixel kernel */
+    RT_TUNE_END = 12           /* one past the last key */
 } rt_tuning;
 
 /* Message of the last failure on the calling thread ("" if none). */
@@ -203,6 +206,15 @@ int rt_read_primary_ids(rt_context *ctx, int32_t *ids);
  */
 int rt_read_counters(rt_context *ctx, uint64_t counters[16]);
 int rt_set_counting(rt_context *ctx, int enable);
+
+/*
+ * Diagnostic, no counterpart in the reference: wave-cycle totals per phase of the instrumented
+ * persistent kernel after a run with counting enabled.  out[0..4]: cycles in node steps, triangle
+ * steps, shadow hand-over, shading, whole kernel (summed over waves); out[8]: traversal turns;
+ * out[9..14]: lanes per state summed over those turns (at an inner node, at a leaf, shadow ray
+ * finished, waiting to be shaded, idle, out of work); the rest 0.
+ */
+int rt_debug_phase_cycles(rt_context *ctx, uint64_t out[16]);
 
 /*
  * The reference's performance counter: performance_counters[0] accumulates

@@ -2,6 +2,8 @@
 // renderer backend.  gfx950 only; build with -ffp-contract=off (see rt_core.h).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <type_traits>
@@ -576,6 +578,7 @@ struct rt_context {
     size_t spill_bytes[3] = {0, 0, 0};
     int next_slot = 0;
     int tune_overlap = 1;
+    int tune_max_stack = 64;
     int tune_shade_wait = 12;
     bool sphere_lights = false; // opt-in extension: emissive spheres are sampled too (one-thread-per-pixel kernel)
     int tune_shade_num = 2, tune_leaf_lanes = 12, tune_blocks_per_cu = 0, tune_batch = 0, tune_sdone_lanes = 2, tune_refill_lanes = 0, tune_max_leaf = 4, tune_tri_cost_x10 = 12, tune_lds_state = RT_LDS_PARK;
@@ -657,6 +660,15 @@ int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchPar
     return RT_OK;
 }
 
+// Entries the persistent kernel's traversal stack must be able to hold for the current scene, and
+// the most any instantiation provides.  A degenerate scene whose 4-wide tree needs more is rendered
+// by the one-thread-per-pixel kernel instead, which walks the binary tree (need <= its depth < 64).
+constexpr uint32_t kMaxStackEntries = 64;
+uint32_t persistent_stack_need(const rt_context *c)
+{
+    return rt::kWideBvh ? c->host_scene.max_stack4 : c->host_scene.max_depth;
+}
+
 using CfgSmall = LaneCfg<RT_PARK2_STACK, RT_PARK2_SLOTS, RT_PARK2_MINW, true, false>;
 using CfgSmallDeep = LaneCfg<32, 12, RT_MINW, true, false>;
 using CfgLarge = LaneCfg<RT_LARGE_STACK, RT_LARGE_SLOTS, RT_LARGE_MINW, false, false>;
@@ -667,8 +679,8 @@ template <bool COUNT, bool FUSED>
 int launch_persistent_d(rt_context *c, const rt::FrameParams &fp, const BatchParams &bp, unsigned int *counter, hipStream_t stream)
 {
     // entries the traversal stack must hold
-    uint32_t depth = rt::kWideBvh ? c->host_scene.max_stack4 : c->host_scene.max_depth;
-    if (depth > 64) return fail(RT_ERR_UNSUPPORTED, "acceleration structure too deep for the traversal stack");
+    uint32_t depth = persistent_stack_need(c);
+    if (depth > kMaxStackEntries) return fail(RT_ERR_UNSUPPORTED, "acceleration structure too deep for the traversal stack");
     if (c->tune_lds_state == 0 || !rt::kWideBvh) return launch_persistent_t<CfgRegisters, COUNT, FUSED>(c, fp, bp, counter, stream);
     // 16-bit links: node indices below 32768 and leaf codes (first << 3 | count - 1) below 32768
     const rt::BuiltScene &hs = c->host_scene;
@@ -868,17 +880,20 @@ void rt_destroy(rt_context *c)
     delete c;
 }
 
-int rt_set_scene(rt_context *c, const void *spheres, uint32_t n_spheres, const void *triangles, uint32_t n_triangles)
+// Builds the acceleration structure and the tables on the host and uploads them.  origin_mag: see
+// rt::BuildOptions (the camera's coordinate magnitude when it is far from the scene, else 0).
+static int upload_scene(rt_context *c, const void *spheres, uint32_t n_spheres, const void *triangles, uint32_t n_triangles,
+                        float origin_mag)
 {
-    if (!c) return fail(RT_ERR_INVALID, "null context");
-    if ((n_spheres && !spheres) || (n_triangles && !triangles)) return fail(RT_ERR_INVALID, "null scene buffer");
-    if (n_triangles >= (1u << 28)) return fail(RT_ERR_UNSUPPORTED, "too many triangles");
     RT_HIP_CHECK(hipSetDevice(c->device));
     RT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (hipStream_t s : c->aux)
+        if (s) RT_HIP_CHECK(hipStreamSynchronize(s));
     c->free_scene();
     rt::BuildOptions opt;
     opt.max_leaf = (uint32_t)c->tune_max_leaf;
     opt.triangle_cost = 0.1f * (float)c->tune_tri_cost_x10;
+    opt.origin_mag = origin_mag;
     rt::build_scene(spheres, n_spheres, triangles, n_triangles, opt, c->host_scene);
     if (c->host_scene.max_depth >= 64) return fail(RT_ERR_UNSUPPORTED, "acceleration structure too deep");
     // the 4-wide node step addresses nodes by a 32-bit byte offset
@@ -900,6 +915,34 @@ int rt_set_scene(rt_context *c, const void *spheres, uint32_t n_spheres, const v
     v.total_power = hs.total_power; v.root = hs.root;
     c->has_scene = true;
     return RT_OK;
+}
+
+// Largest coordinate magnitude of the camera position in the stored uniforms (0 if not finite).
+static float camera_magnitude(const rt_context *c)
+{
+    float m = std::max(std::fabs(c->uniforms[0]), std::max(std::fabs(c->uniforms[1]), std::fabs(c->uniforms[2])));
+    return m < INFINITY ? m : 0.0f;
+}
+
+int rt_set_scene(rt_context *c, const void *spheres, uint32_t n_spheres, const void *triangles, uint32_t n_triangles)
+{
+    if (!c) return fail(RT_ERR_INVALID, "null context");
+    if ((n_spheres && !spheres) || (n_triangles && !triangles)) return fail(RT_ERR_INVALID, "null scene buffer");
+    if (n_triangles >= (1u << 28)) return fail(RT_ERR_UNSUPPORTED, "too many triangles");
+    float cam = c->has_uniforms ? camera_magnitude(c) : 0.0f;
+    return upload_scene(c, spheres, n_spheres, triangles, n_triangles, cam > rt::kOriginMagCovered ? 2.0f * cam : 0.0f);
+}
+
+// The boxes of the acceleration structure are padded for ray origins up to host_scene.origin_mag.  A
+// camera further out than that (and than the fixed margin covers) gets the structure rebuilt with
+// wider boxes, for twice its distance so that a moving camera does not rebuild every frame.
+static int ensure_padding_covers_camera(rt_context *c)
+{
+    float cam = camera_magnitude(c);
+    if (!(cam > rt::kOriginMagCovered) || !(cam > c->host_scene.origin_mag)) return RT_OK;
+    std::vector<rt::f4> spheres = c->host_scene.spheres, tris = c->host_scene.tri_raw;
+    return upload_scene(c, spheres.data(), c->host_scene.n_spheres, tris.data(), c->host_scene.n_tris,
+                        std::min(2.0f * cam, 1e30f));
 }
 
 int rt_set_uniforms(rt_context *c, const void *uniforms80)
@@ -952,6 +995,7 @@ int rt_set_tuning(rt_context *c, int key, int value)
     case RT_TUNE_OVERLAP_FRAMES: if (value < 0 || value > 1) return fail(RT_ERR_INVALID, "overlap_frames out of range"); c->tune_overlap = value; break;
     case RT_TUNE_SHADE_WAIT: if (value < 0 || value > 1000) return fail(RT_ERR_INVALID, "shade_wait out of range"); c->tune_shade_wait = value; break;
     case RT_TUNE_LDS_STATE: if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "lds_state out of range"); c->tune_lds_state = value; break;
+    case RT_TUNE_MAX_STACK: if (value < 1 || value > (int)kMaxStackEntries) return fail(RT_ERR_INVALID, "max_stack out of range"); c->tune_max_stack = value; break;
     case RT_TUNE_SHADOW_DONE_LANES: if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "shadow_done_lanes out of range"); c->tune_sdone_lanes = value; break;
     default: return fail(RT_ERR_INVALID, "unknown tuning key");
     }
@@ -966,8 +1010,9 @@ static int render_frames_impl(rt_context *c, uint32_t first_frame_index, uint32_
     if (n_frames && (uint64_t)first_frame_index + (uint64_t)(n_frames - 1) * stride >= (1ull << 24))
         return fail(RT_ERR_INVALID, "frame index beyond 2^24 is not exact in the f32 uniform");
     RT_HIP_CHECK(hipSetDevice(c->device));
+    if ((rc = ensure_padding_covers_camera(c))) return rc;
     RT_HIP_CHECK(hipEventRecord(c->ev_start, c->stream));
-    if (c->mode == RT_MODE_BVH && !c->sphere_lights) {
+    if (c->mode == RT_MODE_BVH && !c->sphere_lights && persistent_stack_need(c) <= (uint32_t)c->tune_max_stack) {
         if ((rc = launch_persistent(c, first_frame_index, n_frames, stride, sum))) return rc;
     } else {
         for (uint32_t k = 0; k < n_frames; k++) {

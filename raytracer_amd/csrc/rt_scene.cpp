@@ -50,7 +50,11 @@ struct BuildNode {
 // The box of one triangle, widened so that any ray the Moeller-Trumbore test
 // accepts also meets the box: the test works in f32 and can accept rays that
 // pass a few 1e-5 outside the exact triangle; the margin is orders above that.
-Box padded_triangle_box(const float *rec)
+// Both that slack and the rounding of the fused box test (o * (1/d) and the
+// reciprocal itself, about 1e-7 relative each) scale with the magnitude of the
+// ray origin: the fixed 2e-4 covers origins up to kOriginMagCovered, beyond
+// that the margin grows by 2e-6 per unit of origin magnitude.
+Box padded_triangle_box(const float *rec, float origin_mag)
 {
     Box b;
     b.reset();
@@ -60,7 +64,7 @@ Box padded_triangle_box(const float *rec)
     float ext = std::max(b.hi[0] - b.lo[0], std::max(b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]));
     float mag = 0.0f;
     for (int a = 0; a < 3; a++) mag = std::max(mag, std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
-    float pad = 2e-4f + 1e-3f * ext + 4e-6f * mag;
+    float pad = 2e-4f + 1e-3f * ext + 4e-6f * mag + 2e-6f * std::max(0.0f, origin_mag - kOriginMagCovered);
     for (int a = 0; a < 3; a++) { b.lo[a] -= pad; b.hi[a] += pad; }
     return b;
 }
@@ -259,12 +263,30 @@ void build_scene(const void *spheres, uint32_t n_spheres, const void *triangles,
     // "var selected_triangle: Triangle;" left unassigned is the zero triangle.
     push_light(mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), 0.0f, false);
 
+    // Coordinate magnitude of the geometry: shadow and bounce rays start anywhere on it.
+    float coord_mag = 0.0f;
+    for (uint32_t i = 0; i < n_tris; i++)
+        for (int v = 0; v < 3; v++)
+            for (int a = 0; a < 3; a++) {
+                float x = std::fabs(T[(size_t)i * 24 + 4 * v + a]);
+                if (x < std::numeric_limits<float>::infinity()) coord_mag = std::max(coord_mag, x);
+            }
+    for (uint32_t i = 0; i < n_spheres; i++) {
+        const float *sp = (const float *)out.spheres.data() + (size_t)i * 16;
+        for (int a = 0; a < 3; a++) {
+            float x = std::fabs(sp[a]) + std::fabs(sp[3]);
+            if (x < std::numeric_limits<float>::infinity()) coord_mag = std::max(coord_mag, x);
+        }
+    }
+    out.coord_mag = coord_mag;
+    out.origin_mag = std::max(opt.origin_mag, coord_mag);
+
     // BVH over padded triangle boxes.
     if (n_tris == 0) return;
     std::vector<Prim> prims(n_tris);
     for (uint32_t i = 0; i < n_tris; i++) {
         const float *r = T + (size_t)i * 24;
-        prims[i].box = padded_triangle_box(r);
+        prims[i].box = padded_triangle_box(r, out.origin_mag);
         for (int a = 0; a < 3; a++) prims[i].centroid[a] = 0.5f * (prims[i].box.lo[a] + prims[i].box.hi[a]);
         prims[i].index = i;
     }

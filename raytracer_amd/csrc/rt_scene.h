@@ -18,6 +18,8 @@ struct BuiltScene {
     int32_t root = kNoRoot, root4 = kNoRoot;
     uint32_t n_leaves = 0, max_depth = 0;
     uint32_t max_stack4 = 0; // entries the 4-wide traversal can have on its stack at once
+    float coord_mag = 0.0f;  // largest coordinate magnitude of the geometry (triangle vertices, sphere extents)
+    float origin_mag = 0.0f; // the BuildOptions::origin_mag the boxes were padded for
 };
 
 struct BuildOptions {
@@ -25,7 +27,12 @@ struct BuildOptions {
     uint32_t max_depth = 60;  // deepest leaf allowed (traversal stack bound)
     float traversal_cost = 1.0f;
     float triangle_cost = 1.2f;
+    // Largest coordinate magnitude of any ray origin the tree must serve (camera position, scene
+    // extent).  The rounding of the box test and of the triangle test's o - v0 grows with it, so
+    // boxes are widened in proportion once it exceeds kOriginMagCovered.
+    float origin_mag = 0.0f;
 };
+constexpr float kOriginMagCovered = 100.0f; // origins up to here are covered by the fixed part of the padding
 
 // spheres: n_spheres records of 64 bytes; triangles: n_tris records of 96 bytes
 // (src/gpu-schemas.ts:19-38).

@@ -42,14 +42,27 @@ static int get_args(napi_env env, napi_callback_info info, size_t want, napi_val
     return 1;
 }
 
-static rt_context *get_ctx(napi_env env, napi_value v)
+/* What a JS renderer handle points at: the context (NULL after destroy) and the image size it was
+ * created with, which sizes every read-back buffer. */
+typedef struct handle_box {
+    rt_context *ctx;
+    uint32_t width, height;
+} handle_box;
+
+static handle_box *get_box(napi_env env, napi_value v)
 {
     void *p = NULL;
     if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
         napi_throw_type_error(env, NULL, "expected a renderer handle");
         return NULL;
     }
-    return *(rt_context **)p; /* NULL after destroy */
+    return (handle_box *)p;
+}
+
+static rt_context *get_ctx(napi_env env, napi_value v)
+{
+    handle_box *box = get_box(env, v);
+    return box ? box->ctx : NULL; /* NULL after destroy */
 }
 
 static int get_i32(napi_env env, napi_value v, int32_t *out)
@@ -88,8 +101,8 @@ static int get_f32_array(napi_env env, napi_value v, float **data, size_t *len)
 static void finalize_handle(napi_env env, void *data, void *hint)
 {
     (void)env; (void)hint;
-    rt_context **box = (rt_context **)data;
-    if (*box) rt_destroy(*box);
+    handle_box *box = (handle_box *)data;
+    if (box->ctx) rt_destroy(box->ctx);
     free(box);
 }
 
@@ -110,9 +123,11 @@ static napi_value js_create(napi_env env, napi_callback_info info)
         if (!get_i32(env, a[i], &v[i])) return NULL;
     rt_context *ctx = NULL;
     if (rt_create(v[0], v[1], v[2], v[3], v[4], v[5], &ctx) != RT_OK) return throw_rt(env, "rt_create");
-    rt_context **box = (rt_context **)malloc(sizeof *box);
+    handle_box *box = (handle_box *)malloc(sizeof *box);
     if (!box) { rt_destroy(ctx); napi_throw_error(env, NULL, "out of memory"); return NULL; }
-    *box = ctx;
+    box->ctx = ctx;
+    box->width = (uint32_t)v[1];
+    box->height = (uint32_t)v[2];
     napi_value out;
     if (napi_create_external(env, box, finalize_handle, NULL, &out) != napi_ok) {
         rt_destroy(ctx); free(box);
@@ -131,8 +146,8 @@ static napi_value js_destroy(napi_env env, napi_callback_info info)
         napi_throw_type_error(env, NULL, "expected a renderer handle");
         return NULL;
     }
-    rt_context **box = (rt_context **)p;
-    if (*box) { rt_destroy(*box); *box = NULL; }
+    handle_box *box = (handle_box *)p;
+    if (box->ctx) { rt_destroy(box->ctx); box->ctx = NULL; }
     return NULL;
 }
 
@@ -243,16 +258,23 @@ static napi_value js_last_render_ms(napi_env env, napi_callback_info info)
     return out;
 }
 
-/* read-backs into a fresh typed array sized from (width, height) passed by the caller */
+/* Read-backs into a fresh typed array.  The library always writes the context's own width x height
+ * elements, so the buffer is sized from the size the handle was created with; the (width, height)
+ * the caller passes must agree with it. */
 static napi_value read_into(napi_env env, napi_callback_info info, napi_typedarray_type type, size_t elem_bytes,
                             size_t per_pixel, int which)
 {
     napi_value a[3], ab, out;
     if (!get_args(env, info, 3, a)) return NULL;
     NEED_CTX(ctx, a[0]);
+    handle_box *box = get_box(env, a[0]);
     uint32_t w, h;
     if (!get_u32(env, a[1], &w) || !get_u32(env, a[2], &h)) return NULL;
-    size_t n = (size_t)w * h * per_pixel;
+    if (w != box->width || h != box->height) {
+        napi_throw_range_error(env, NULL, "read-back size differs from the size the renderer was created with");
+        return NULL;
+    }
+    size_t n = (size_t)box->width * box->height * per_pixel;
     void *data = NULL;
     NAPI_OK(napi_create_arraybuffer(env, n * elem_bytes, &data, &ab));
     int rc = which == 0 ? rt_read_accum(ctx, (float *)data)

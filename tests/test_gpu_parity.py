@@ -430,3 +430,27 @@ def test_sphere_light_extension(mode):
         assert np.array_equal(ctx.read_accum(), orc.accum_rgb())
         assert int(ctx.read_counters()[0]) == int(orc.counters[0])
         ctx.close()
+
+
+@pytest.mark.parametrize("distance,fov", [(1000.0, 0.4), (30000.0, 0.013)])
+def test_far_camera_bvh_vs_brute_force_and_oracle(scenes, distance, fov):
+    """A camera thousands of units from the geometry, zoomed in: the f32 slack of the triangle test
+    and of the box test grows with the ray origin's magnitude, so the acceleration structure is
+    rebuilt with wider boxes when the camera is placed (the scene was uploaded before the uniforms)."""
+    import copy
+
+    base = scenes["suzanne"]
+    cam = copy.deepcopy(base.camera)
+    cam["position"] = [0.3, 1.2, distance]
+    cam["fov"] = fov
+    scene = S.Scene(camera=cam, spheres=base.spheres, triangles=base.triangles)
+    for mode in (capi.RT_MODE_BVH, capi.RT_MODE_BVH_TILES, capi.RT_MODE_BRUTE_FORCE):
+        run_pair(scene, 96, 54, 2, 2, mode)
+    run_batched(scene, 96, 54, 3, 2, 2)
+
+
+def test_tree_deeper_than_the_accepted_stack_goes_to_the_tile_kernel(scenes):
+    """RT_TUNE_MAX_STACK below the scene's stack need: the default mode must hand the frames to the
+    one-thread-per-pixel kernel instead of failing, single frames and batches alike."""
+    run_pair(scenes["suzanne"], 100, 61, 2, 3, capi.RT_MODE_BVH, tuning=((capi.RT_TUNE_MAX_STACK, 4),))
+    run_batched(scenes["suzanne"], 100, 61, 3, 2, 2, tuning=((capi.RT_TUNE_MAX_STACK, 4),))
