@@ -156,6 +156,27 @@ int rt_render_frame(rt_context *ctx);
  */
 int rt_render_frames(rt_context *ctx, uint32_t first_frame_index, uint32_t n_frames);
 
+/*
+ * rt_render_frames for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same
+ * result as rt_render_frames, bit for bit, through the same kernels; the per-launch work counter
+ * and the frame colours of a launch, which rt_render_frames keeps in buffers it allocates on
+ * demand, live in a fixed 64 MiB + 256 B device array that is part of the library image (each GPU
+ * the library runs on holds one until the process ends).  Calls no hipMalloc / hipFree.
+ * Limits, reported as RT_ERR_UNSUPPORTED with a message:
+ *   - the context may own at most 8,388,608 pixels (64 MiB / 8 B; a 3840x2160 image fits);
+ *     frames per launch are limited to what fits, so very large images trace one frame per launch;
+ *   - scenes whose traversal needs the stack overflow area in global memory (4-wide trees deeper
+ *     than 16 entries over more than 4096 triangles) must have been rendered once with
+ *     rt_render_frames, which allocates that area;
+ *   - a camera that moved so far out that the acceleration structure must be rebuilt is refused.
+ * All contexts on one GPU share that GPU's array, on their own streams: calls on different
+ * contexts of one GPU must not overlap in time (finish one with rt_sync before starting another),
+ * or they race on the array.  The array keeps the previous call's contents; the counter is
+ * cleared at the start of every launch and the colours are written before they are read.
+ */
+int rt_render_frames_noalloc(rt_context *ctx, uint32_t first_frame_index, uint32_t n_frames);
+
 /* Wait for all submitted work of the context. */
 int rt_sync(rt_context *ctx);
 

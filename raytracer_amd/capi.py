@@ -37,6 +37,7 @@ SYMBOLS = {
     "rt_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rt_render_frame": (C.c_int, [C.c_void_p]),
     "rt_render_frames": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "rt_render_frames_noalloc": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "rt_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_sync": (C.c_int, [C.c_void_p]),
     "rt_last_render_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
@@ -162,6 +163,9 @@ class Context:
 
     def render_frames(self, first_frame_index: int, n: int):
         _check(self.lib.rt_render_frames(self.handle, first_frame_index, n))
+
+    def render_frames_noalloc(self, first_frame_index: int, n: int):
+        _check(self.lib.rt_render_frames_noalloc(self.handle, first_frame_index, n))
 
     def sync(self):
         _check(self.lib.rt_sync(self.handle))

@@ -34,6 +34,35 @@ int fail(int code, const std::string &msg)
             return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));       \
     } while (0)
 
+// ---------------------------------------------------------------------------
+// Workspace of rt_render_frames_noalloc: a fixed device array, so that entry point never allocates.
+// Layout: [0, kScratchHeader) the work counter of the launch in flight; then the rgba16float
+// colours of the frames of one launch (what rt_render_frames keeps in a hipMalloc'ed batch buffer).
+// Every GPU the library runs on holds its own copy of the array until the process ends.  In host
+// code the array's name is only a handle: its device address comes from hipGetSymbolAddress, once per
+// device (scratch_of), and only that pointer is ever passed to kernels and memsets.
+// ---------------------------------------------------------------------------
+constexpr size_t kScratchHeader = 256;
+constexpr size_t kScratchColorBytes = (size_t)64 << 20; // 8,388,608 pixel-frames: one 3840x2160 frame, four 1920x1080 frames
+static __device__ __align__(256) unsigned char scratch[kScratchHeader + kScratchColorBytes];
+
+constexpr int kMaxDevices = 64;
+void *g_scratch_ptr[kMaxDevices] = {nullptr};
+
+// Device address of `scratch` on `device`, which must be the current device.
+int scratch_of(int device, void **out)
+{
+    if (device < 0 || device >= kMaxDevices) return fail(RT_ERR_UNSUPPORTED, "device index beyond the library's table");
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        RT_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(RT_ERR_DEVICE, "hipGetSymbolAddress returned a null workspace address");
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return RT_OK;
+}
+
 // Which image rows a context renders: local row l maps to global row
 // ((l / rows) * count + index) * rows + l % rows  (8-row stripes dealt round-robin).
 struct StripeMap {
@@ -541,6 +570,8 @@ struct rt_context {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
+    void *scratch = nullptr; // this device's copy of the fixed workspace (rt_render_frames_noalloc)
+    bool no_alloc = false;   // set for the duration of an rt_render_frames_noalloc call
 
     FrameBuffers fb{nullptr, nullptr, nullptr, nullptr};
 
@@ -640,6 +671,9 @@ int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchPar
         int which = stream == c->stream ? 0 : (stream == c->aux[0] ? 1 : 2);
         size_t need = (size_t)blocks * kBlock * kSpillEntries * sizeof(int32_t);
         if (c->spill_bytes[which] < need) {
+            if (c->no_alloc)
+                return fail(RT_ERR_UNSUPPORTED, "this scene's traversal needs the stack overflow area in global memory, which "
+                                                "rt_render_frames_noalloc cannot allocate; render once with rt_render_frames first");
             RT_HIP_CHECK(hipStreamSynchronize(stream));
             (void)hipFree(c->d_spill[which]);
             c->d_spill[which] = nullptr;
@@ -728,11 +762,19 @@ int launch_persistent(rt_context *c, uint32_t first, uint32_t n, uint32_t stride
     size_t local_px = (size_t)c->local_rows * c->width;
     if (local_px == 0 || n == 0) return RT_OK;
     uint32_t max_batch = frames_per_launch(c);
+    if (c->no_alloc) {
+        // the workspace holds the frame colours of one launch
+        if (local_px * sizeof(uint2) > kScratchColorBytes)
+            return fail(RT_ERR_UNSUPPORTED, "rt_render_frames_noalloc: the context owns " + std::to_string(local_px) +
+                                            " pixels, the fixed workspace holds " + std::to_string(kScratchColorBytes / sizeof(uint2)));
+        max_batch = (uint32_t)std::min<uint64_t>(max_batch, kScratchColorBytes / (local_px * sizeof(uint2)));
+    }
     uint32_t done = 0;
     while (done < n) {
         uint32_t b = std::min(max_batch, n - done);
         unsigned int *counter = c->d_work + c->work_used;
         c->work_used = (c->work_used + 1) % kWorkCounters;
+        if (c->no_alloc) counter = (unsigned int *)c->scratch; // launches on one stream run in order: one counter is enough
         c->uniforms[12] = (float)(first + done * stride);
         rt::FrameParams fp;
         std::string err;
@@ -740,7 +782,17 @@ int launch_persistent(rt_context *c, uint32_t first, uint32_t n, uint32_t stride
         BatchParams bp{first + done * stride, b, nullptr, stride, sum, c->fb.ids, false};
         dim3 acc_grid((unsigned)((local_px + 255) / 256));
         int rc;
-        if (b == 1 && !c->tune_overlap) {
+        if (c->no_alloc) {
+            // same kernels as the batch path below, colours in the fixed workspace
+            bp.colors = (uint2 *)((unsigned char *)c->scratch + kScratchHeader);
+            RT_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned int), c->stream));
+            rc = c->counting ? launch_persistent_d<true, false>(c, fp, bp, counter, c->stream)
+                             : launch_persistent_d<false, false>(c, fp, bp, counter, c->stream);
+            if (rc) return rc;
+            hipLaunchKernelGGL(accumulate_batch_kernel, acc_grid, dim3(256), 0, c->stream, c->fb, bp, c->width, c->height,
+                               c->local_rows, c->sm);
+            RT_HIP_CHECK(hipGetLastError());
+        } else if (b == 1 && !c->tune_overlap) {
             // one frame, accumulated by the trace kernel itself
             RT_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned int), c->stream));
             rc = c->counting ? launch_persistent_d<true, true>(c, fp, bp, counter, c->stream)
@@ -835,6 +887,10 @@ int rt_create(int device, int width, int height, int stripe_rows, int stripe_ind
     c->height = height;
     c->sm = StripeMap{stripe_rows, stripe_index, stripe_count};
     c->local_rows = owned_rows_of(height, c->sm);
+    {
+        int rc = scratch_of(device, &c->scratch);
+        if (rc) { rt_destroy(c); return rc; }
+    }
 
     size_t px = (size_t)width * height;
     auto cleanup = [&](int code) { rt_destroy(c); return code; };
@@ -940,6 +996,9 @@ static int ensure_padding_covers_camera(rt_context *c)
 {
     float cam = camera_magnitude(c);
     if (!(cam > rt::kOriginMagCovered) || !(cam > c->host_scene.origin_mag)) return RT_OK;
+    if (c->no_alloc)
+        return fail(RT_ERR_UNSUPPORTED, "the camera moved beyond the range the acceleration structure was built for; "
+                                        "rebuilding it allocates, which rt_render_frames_noalloc must not");
     std::vector<rt::f4> spheres = c->host_scene.spheres, tris = c->host_scene.tri_raw;
     return upload_scene(c, spheres.data(), c->host_scene.n_spheres, tris.data(), c->host_scene.n_tris,
                         std::min(2.0f * cam, 1e30f));
@@ -1032,6 +1091,15 @@ static int render_frames_impl(rt_context *c, uint32_t first_frame_index, uint32_
 int rt_render_frames(rt_context *c, uint32_t first_frame_index, uint32_t n_frames)
 {
     return render_frames_impl(c, first_frame_index, n_frames, 1, false);
+}
+
+int rt_render_frames_noalloc(rt_context *c, uint32_t first_frame_index, uint32_t n_frames)
+{
+    if (!c) return fail(RT_ERR_INVALID, "null context");
+    c->no_alloc = true;
+    int rc = render_frames_impl(c, first_frame_index, n_frames, 1, false);
+    c->no_alloc = false;
+    return rc;
 }
 
 int rt_render_frame_sums(rt_context *c, uint32_t first_frame_index, uint32_t n_frames, uint32_t stride)
