@@ -219,7 +219,7 @@ RT_HD float triangle_t(f3 ro, f3 rd, f3 v0, f3 e01, f3 e02)
 // ---------------------------------------------------------------------------
 
 struct RayBox {
-    f3 inv, ood; // 1/d and o/d
+    f3 inv, ood; // 1/d and -(o/d): the slab distance of a plane at x is fma(x, inv, ood)
 };
 
 RT_HD float fast_rcp(float x)
@@ -238,7 +238,7 @@ RT_HD RayBox make_raybox(f3 o, f3 d)
     // distances; a huge finite reciprocal keeps them finite with the right signs.
     r.inv = mk3(clampf(fast_rcp(d.x), -1e30f, 1e30f), clampf(fast_rcp(d.y), -1e30f, 1e30f),
                 clampf(fast_rcp(d.z), -1e30f, 1e30f));
-    r.ood = mk3(o.x * r.inv.x, o.y * r.inv.y, o.z * r.inv.z);
+    r.ood = mk3(-(o.x * r.inv.x), -(o.y * r.inv.y), -(o.z * r.inv.z));
     return r;
 }
 
@@ -248,9 +248,9 @@ RT_HD RayBox make_raybox(f3 o, f3 d)
 RT_HD bool slab(const RayBox &rb, float lox, float loy, float loz, float hix, float hiy, float hiz,
                 float tmax, float &tnear)
 {
-    float ax = __builtin_fmaf(lox, rb.inv.x, -rb.ood.x), bx = __builtin_fmaf(hix, rb.inv.x, -rb.ood.x);
-    float ay = __builtin_fmaf(loy, rb.inv.y, -rb.ood.y), by = __builtin_fmaf(hiy, rb.inv.y, -rb.ood.y);
-    float az = __builtin_fmaf(loz, rb.inv.z, -rb.ood.z), bz = __builtin_fmaf(hiz, rb.inv.z, -rb.ood.z);
+    float ax = __builtin_fmaf(lox, rb.inv.x, rb.ood.x), bx = __builtin_fmaf(hix, rb.inv.x, rb.ood.x);
+    float ay = __builtin_fmaf(loy, rb.inv.y, rb.ood.y), by = __builtin_fmaf(hiy, rb.inv.y, rb.ood.y);
+    float az = __builtin_fmaf(loz, rb.inv.z, rb.ood.z), bz = __builtin_fmaf(hiz, rb.inv.z, rb.ood.z);
     float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
     float f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
     tnear = n;
@@ -409,8 +409,11 @@ RT_HD Hit fetch_hit(const SceneView &sc, f3 ro, f3 rd, int32_t id, float t)
     if ((uint32_t)id < sc.n_spheres) {
         const f4 *s = sc.spheres + 4 * (size_t)id;
         f4 s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3];
+        // The normal is taken at the parameter of the branch that reported the hit (common.wgsl:155-165):
+        // a reported t above 0.01 can only come from the t1 branch, whose parameter is t itself; the
+        // t2 branch reports t1 <= 0.01 and needs the roots again.
         float tn = t;
-        (void)sphere_t(ro, rd, s0, tn);
+        if (!(t > 0.01f)) (void)sphere_t(ro, rd, s0, tn);
         f3 hit_point = add(ro, scale(rd, tn));
         h.normal = normalize(sub(hit_point, xyz(s0)));
         h.color = xyz(s1);

@@ -78,20 +78,23 @@ __host__ __device__ inline int stripe_global_row(const StripeMap &m, int local)
 // Per-lane traversal stack in LDS: entry k of lane l lives at base[k * BLOCK + l],
 // so one wave's pushes/pops touch 64 consecutive dwords (no bank conflicts).
 // ---------------------------------------------------------------------------
+#ifndef RT_LEAF_LOOP
+#define RT_LEAF_LOOP 0 // 1: a triangle step tests every triangle of the leaf, not only the next one
+#endif
 #ifndef RT_LDS_PARK
 #define RT_LDS_PARK 2
 #endif
 #ifndef RT_PARK2_STACK
-#define RT_PARK2_STACK 24
+#define RT_PARK2_STACK 22
 #endif
 #ifndef RT_PARK2_SLOTS
-#define RT_PARK2_SLOTS 14
+#define RT_PARK2_SLOTS 15
 #endif
 #ifndef RT_LARGE_STACK
 #define RT_LARGE_STACK 16 // large scenes (32-bit links): stack entries in LDS, the rest in global memory
 #endif
 #ifndef RT_LARGE_SLOTS
-#define RT_LARGE_SLOTS 12
+#define RT_LARGE_SLOTS 14
 #endif
 #ifndef RT_LARGE_MINW
 #define RT_LARGE_MINW 5
@@ -125,7 +128,7 @@ struct LdsStack {
 
 // How an instantiation of the persistent kernel keeps its per-lane state.
 //   STACK  traversal stack entries in LDS
-//   PARK   dwords of rarely touched lane state kept in LDS (0: all in registers; 12: what is set
+//   PARK   dwords of rarely touched lane state kept in LDS (0: all in registers; 14: what is set
 //          aside during shadow rays; more: per-pixel values too)
 //   MINW   waves per SIMD it is compiled for: 6 (80 VGPRs) needs STACK * entry size + PARK * 4 <=
 //          104 bytes per lane (26 KB per block, six blocks in a CU's 160 KB); 5 (96 VGPRs) needs it
@@ -414,7 +417,18 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
             bool any_inner = __ballot(L.mode == rt::kLaneTraverse && rt::link_is_inner(L.cur)) != 0ull;
             if (n_leaf != 0 && (n_leaf >= sched.leaf_lanes || !any_inner)) {
                 if (COUNT) { ph_leaf_it++; ph_leaf_ln += n_leaf; tc0 = clock64(); }
+#if RT_LEAF_LOOP
+                // all triangles of the leaf in one go (lanes with fewer triangles idle in the later rounds)
+                int rounds = leaf ? (int)((uint32_t)~L.cur & 7u) + 1 : 0;
+                while (__ballot(rounds > 0) != 0ull) {
+                    if (rounds > 0) {
+                        rt::lane_step_triangle(sc, L, stack, cp);
+                        rounds = L.mode == rt::kLaneTraverse ? rounds - 1 : 0;
+                    }
+                }
+#else
                 if (leaf) rt::lane_step_triangle(sc, L, stack, cp);
+#endif
                 if (COUNT) tc_tri += clock64() - tc0;
             }
 
@@ -704,7 +718,7 @@ uint32_t persistent_stack_need(const rt_context *c)
 }
 
 using CfgSmall = LaneCfg<RT_PARK2_STACK, RT_PARK2_SLOTS, RT_PARK2_MINW, true, false>;
-using CfgSmallDeep = LaneCfg<32, 12, RT_MINW, true, false>;
+using CfgSmallDeep = LaneCfg<32, 14, RT_MINW, true, false>;
 using CfgLarge = LaneCfg<RT_LARGE_STACK, RT_LARGE_SLOTS, RT_LARGE_MINW, false, false>;
 using CfgLargeDeep = LaneCfg<RT_LARGE_STACK, RT_LARGE_SLOTS, RT_LARGE_MINW, false, true>;
 using CfgRegisters = LaneCfg<64, 0, 2, false, false>; // 64 KB of LDS per block: two blocks per CU

@@ -70,16 +70,17 @@ struct Lane {
 
 // State a lane touches rarely, kept behind a `Park` policy (put(slot, value) / get(slot) on
 // kParkFloats floats) so that the kernel can hold it in LDS instead of registers:
-//  - what is set aside while a shadow ray is in flight (slots 0-11): the next bounce ray and
-//    the two pending additions to `light`, written by lane_shade_closest, read back by
-//    lane_shadow_done;
-//  - what lives for a whole pixel-frame (slots 12-19): the camera ray direction, its
+//  - what is set aside while a shadow ray is in flight (slots 0-13): the next bounce ray, the
+//    result of its sphere tests (done while the bounce is shaded, when most lanes of the wave are
+//    active, rather than when the shadow ray ends, when few are) and the two pending additions to
+//    `light`, written by lane_shade_closest, read back by lane_shadow_done;
+//  - what lives for a whole pixel-frame (slots 14-21): the camera ray direction, its
 //    closest hit (every sample of a frame starts on the same ray, raytracer_compute.wgsl:329-336,
 //    so it is traced once) and the sum of the samples' radiance.
 // RegPark keeps everything in registers.
 enum {
-    kParkNextO = 0, kParkNextD = 3, kParkNee = 6, kParkEm = 9, kParkShadowFloats = 12,
-    kParkTotal = 12, kParkPrimT = 15, kParkPrimId = 16, kParkPrimD = 17, kParkFloats = 20
+    kParkNextO = 0, kParkNextD = 3, kParkNee = 6, kParkEm = 9, kParkNextT = 12, kParkNextId = 13, kParkShadowFloats = 14,
+    kParkTotal = 14, kParkPrimT = 17, kParkPrimId = 18, kParkPrimD = 19, kParkFloats = 22
 };
 
 struct RegPark {
@@ -169,6 +170,39 @@ RT_HD void lane_launch_ray(const SceneView &sc, Lane &L, Stack &stack, bool anyh
     if (L.cur == kNoRoot) L.mode = anyhit ? kLaneShadowDone : kLaneShadeClosest;
 }
 
+// The sphere part of a closest-hit ray_all for a ray that is launched later (the bounce ray set
+// aside behind a shadow ray): best t and id over the spheres, (INFINITY, kNoHit) if none.
+RT_HD void spheres_closest(const SceneView &sc, f3 o, f3 d, float &best_t, int32_t &best_id, TestCounts *cnt)
+{
+    best_t = INFINITY;
+    best_id = kNoHit;
+    if (all_nan(d)) return;
+    for (uint32_t i = 0; i < sc.n_spheres; i++) {
+        float tn;
+        float t = sphere_t(o, d, sc.spheres[4 * i], tn);
+        if (cnt) cnt->spheres++;
+        if (t > 0.0f && (t < best_t || (t == best_t && (int32_t)i < best_id))) { best_t = t; best_id = (int32_t)i; }
+    }
+}
+
+// Starts the closest-hit ray_all of the lane's ray (L.o, L.d) whose sphere tests were done before
+// (spheres_closest): only the tree is left to traverse.
+template <class Stack>
+RT_HD void lane_launch_pretested(const SceneView &sc, Lane &L, Stack &stack, float best_t, int32_t best_id, RayCounts &n_rays)
+{
+    n_rays.calls++;
+    n_rays.traversed++;
+    lane_set_flag(L, kBitAnyhit, false);
+    L.tmax = best_t;
+    L.best_id = best_id;
+    L.mode = kLaneTraverse;
+    stack.reset();
+    L.cur = kWideBvh ? sc.root4 : sc.root;
+    if (all_nan(L.d)) L.cur = kNoRoot;
+    else L.rb = make_raybox(L.o, L.d);
+    if (L.cur == kNoRoot) L.mode = kLaneShadeClosest;
+}
+
 // One visit of a node of the binary tree (used when RT_WIDE_BVH is 0): the nearer hit child is
 // visited next, the other goes on the stack.
 template <class Stack>
@@ -190,43 +224,19 @@ RT_HD void lane_step_inner(const SceneView &sc, Lane &L, Stack &stack, TestCount
     else lane_pop(L, stack);
 }
 
-// a[i] * m - s for the four children of a node.  (Packed v_pk_fma_f32 was measured slower here.)
+// a[i] * m + s for the four children of a node.  (Packed v_pk_fma_f32 was measured slower here.)
 RT_HD void fma4(const f4 &a, float m, float s, float out[4])
 {
-    out[0] = __builtin_fmaf(a.x, m, -s); out[1] = __builtin_fmaf(a.y, m, -s);
-    out[2] = __builtin_fmaf(a.z, m, -s); out[3] = __builtin_fmaf(a.w, m, -s);
+    out[0] = __builtin_fmaf(a.x, m, s); out[1] = __builtin_fmaf(a.y, m, s);
+    out[2] = __builtin_fmaf(a.z, m, s); out[3] = __builtin_fmaf(a.w, m, s);
 }
 
-// One visit of a 4-wide node: four slab tests, the nearest hit child is visited
-// next and the other hit children go on the stack (unsorted: the order only
-// affects how much is culled later, never the result).
-// The sign of the ray direction says which plane of each slab is entered first, so
-// the near and far planes are fetched as such (a node stores lo.x[4], lo.y[4],
-// lo.z[4], hi.x[4], hi.y[4], hi.z[4]) and no per-slab min/max is needed; for lo <= hi
-// this gives the same distances as slab().
+// The second half of a 4-wide node visit: given the entry distances tn[] and hit flags h[] of the
+// four children and their links, the nearest hit child is visited next and the other hit children
+// go on the stack.
 template <class Stack>
-RT_HD void lane_step_inner4(const SceneView &sc, Lane &L, Stack &stack, TestCounts *cnt)
+RT_HD void lane_descend4(Lane &L, Stack &stack, const float tn[4], const bool h[4], f4 lk, TestCounts *cnt)
 {
-    const char *node = (const char *)sc.nodes4;
-    uint32_t at = (uint32_t)L.cur << 7;
-    // byte offset of the near plane vector: lo (0/16/32) for a non-negative direction, hi (48/64/80) otherwise
-    uint32_t nx = at | ((uint32_t)((int32_t)f2u(L.rb.inv.x) >> 31) & 48u);
-    uint32_t ny = at | (16u ^ ((uint32_t)((int32_t)f2u(L.rb.inv.y) >> 31) & 80u));
-    uint32_t nz = at | (32u ^ ((uint32_t)((int32_t)f2u(L.rb.inv.z) >> 31) & 112u));
-    f4 nearx = *(const f4 *)(node + nx), farx = *(const f4 *)(node + (nx ^ 48u));
-    f4 neary = *(const f4 *)(node + ny), fary = *(const f4 *)(node + (ny ^ 80u));
-    f4 nearz = *(const f4 *)(node + nz), farz = *(const f4 *)(node + (nz ^ 112u));
-    f4 lk = *(const f4 *)(node + (at | 96u));
-    float ax[4], ay[4], az[4], bx[4], by[4], bz[4], tn[4];
-    fma4(nearx, L.rb.inv.x, L.rb.ood.x, ax); fma4(farx, L.rb.inv.x, L.rb.ood.x, bx);
-    fma4(neary, L.rb.inv.y, L.rb.ood.y, ay); fma4(fary, L.rb.inv.y, L.rb.ood.y, by);
-    fma4(nearz, L.rb.inv.z, L.rb.ood.z, az); fma4(farz, L.rb.inv.z, L.rb.ood.z, bz);
-    bool h[4];
-    for (int i = 0; i < 4; i++) {
-        tn[i] = fmaxf(fmaxf(ax[i], ay[i]), fmaxf(az[i], 0.0f));
-        float tf = fminf(fminf(bx[i], by[i]), fminf(bz[i], L.tmax));
-        h[i] = tn[i] <= tf;
-    }
     float t0 = tn[0], t1 = tn[1], t2 = tn[2], t3 = tn[3];
     int32_t c0 = (int32_t)f2u(lk.x), c1 = (int32_t)f2u(lk.y), c2 = (int32_t)f2u(lk.z), c3 = (int32_t)f2u(lk.w);
     // children 0 and 1 always exist; an unused slot (link kNoRoot) is never a hit whatever its box says
@@ -246,6 +256,44 @@ RT_HD void lane_step_inner4(const SceneView &sc, Lane &L, Stack &stack, TestCoun
     if (h2 && which != 2) stack.push(c2);
     if (h3 && which != 3) stack.push(c3);
     L.cur = next;
+}
+
+// One visit of a 4-wide node: four slab tests, the nearest hit child is visited
+// next and the other hit children go on the stack (unsorted: the order only
+// affects how much is culled later, never the result).
+// The sign of the ray direction says which plane of each slab is entered first, so
+// the near and far planes are fetched as such (a node stores lo.x[4], lo.y[4],
+// lo.z[4], hi.x[4], hi.y[4], hi.z[4]) and no per-slab min/max is needed; for lo <= hi
+// this gives the same distances as slab().
+template <class Stack>
+RT_HD void lane_visit4(const char *node, uint32_t at, Lane &L, Stack &stack, TestCounts *cnt)
+{
+    // byte offset of the near plane vector: lo (0/16/32) for a non-negative direction, hi (48/64/80) otherwise
+    uint32_t nx = at | ((uint32_t)((int32_t)f2u(L.rb.inv.x) >> 31) & 48u);
+    uint32_t ny = at | (16u ^ ((uint32_t)((int32_t)f2u(L.rb.inv.y) >> 31) & 80u));
+    uint32_t nz = at | (32u ^ ((uint32_t)((int32_t)f2u(L.rb.inv.z) >> 31) & 112u));
+    f4 nearx = *(const f4 *)(node + nx), farx = *(const f4 *)(node + (nx ^ 48u));
+    f4 neary = *(const f4 *)(node + ny), fary = *(const f4 *)(node + (ny ^ 80u));
+    f4 nearz = *(const f4 *)(node + nz), farz = *(const f4 *)(node + (nz ^ 112u));
+    f4 lk = *(const f4 *)(node + (at | 96u));
+    float ax[4], ay[4], az[4], bx[4], by[4], bz[4], tn[4];
+    fma4(nearx, L.rb.inv.x, L.rb.ood.x, ax); fma4(farx, L.rb.inv.x, L.rb.ood.x, bx);
+    fma4(neary, L.rb.inv.y, L.rb.ood.y, ay); fma4(fary, L.rb.inv.y, L.rb.ood.y, by);
+    fma4(nearz, L.rb.inv.z, L.rb.ood.z, az); fma4(farz, L.rb.inv.z, L.rb.ood.z, bz);
+    bool h[4];
+    for (int i = 0; i < 4; i++) {
+        tn[i] = fmaxf(fmaxf(ax[i], ay[i]), fmaxf(az[i], 0.0f));
+        float tf = fminf(fminf(bx[i], by[i]), fminf(bz[i], L.tmax));
+        h[i] = tn[i] <= tf;
+    }
+    lane_descend4(L, stack, tn, h, lk, cnt);
+}
+
+// One visit of the 4-wide node L.cur.
+template <class Stack>
+RT_HD void lane_step_inner4(const SceneView &sc, Lane &L, Stack &stack, TestCounts *cnt)
+{
+    lane_visit4((const char *)sc.nodes4, (uint32_t)L.cur << 7, L, stack, cnt);
 }
 
 // The node visit of whichever tree the lanes traverse.
@@ -394,6 +442,13 @@ RT_HD void lane_shade_closest(const SceneView &sc, const FrameParams &fp, Lane &
             park_put3(park, kParkNextO, no);
             park_put3(park, kParkNextD, nd);
             park_put3(park, kParkEm, em);
+            if (cont) {
+                float nt;
+                int32_t nid;
+                spheres_closest(sc, no, nd, nt, nid, cnt);
+                park.put(kParkNextT, nt);
+                park.put(kParkNextId, u2f((uint32_t)nid));
+            }
             L.o = add(hit_point, scale(hit.normal, 0.01f));
             L.d = ts.direction;
             launch = true;
@@ -419,7 +474,7 @@ RT_HD void lane_shadow_done(const SceneView &sc, const FrameParams &fp, Lane &L,
     if (lane_flag(L, kBitContinue)) {
         L.o = park_get3(park, kParkNextO);
         L.d = park_get3(park, kParkNextD);
-        lane_launch_ray(sc, L, stack, false, 0.0f, n_rays, cnt);
+        lane_launch_pretested(sc, L, stack, park.get(kParkNextT), (int32_t)f2u(park.get(kParkNextId)), n_rays);
     } else {
         lane_end_path(fp, L, park, n_rays);
     }
