@@ -58,14 +58,17 @@ typedef enum rt_tuning {
     RT_TUNE_TRI_COST_X10 = 7,  /* SAH cost of a triangle test relative to a node visit, in tenths; next rt_set_scene */
     RT_TUNE_LDS_STATE = 8,     /* where lanes keep rarely touched state: 2 = in LDS as far as it fits (default), 1 = scenes
                                   of <= 4096 triangles keep only shadow-ray state there, 0 = all of it in registers    */
-    RT_TUNE_OVERLAP_FRAMES = 9, /* single-frame renders: 1 = trace on alternating side streams so that consecutive
-                                  frames overlap (default), 0 = trace and accumulate in one kernel on the context's stream */
+    RT_TUNE_OVERLAP_FRAMES = 9, /* single-frame launches: trace on this many alternating side streams so that consecutive
+                                  frames overlap (2..4, default 3; 1 = 2); 0 = trace and accumulate in one kernel on the
+                                  context's stream */
     RT_TUNE_SHADE_WAIT = 10,   /* shade finished lanes anyway once they have waited this many traversal turns
                                   (default 12); 0 = never */
     RT_TUNE_MAX_STACK = 11,    /* largest traversal-stack need (entries) the persistent kernel takes on, 1..64 (default
                                   64, all its stack can hold); scenes whose tree needs more are rendered by the
                                   one-thread-per-pixel kernel */
-    RT_TUNE_END = 12           /* one past the last key */
+    RT_TUNE_COALESCE_FRAMES = 12, /* rt_render_frame: most frames held back and launched as one batch while the GPU is
+                                  busy with earlier ones (default 16); 0 or 1 = every call launches its frame */
+    RT_TUNE_END = 13           /* one past the last key */
 } rt_tuning;
 
 /* Message of the last failure on the calling thread ("" if none). */
@@ -139,11 +142,17 @@ int rt_set_tuning(rt_context *ctx, int key, int value);
  * (dispatchWorkgroups, src/webgpu-renderer.ts:253-260) followed by the
  * accumulator pass (src/accumulator.ts:63-78), as one submission
  * (src/webgpu-renderer.ts:267).  Asynchronous, like the reference's
- * fire-and-forget submit: frames submitted back to back are traced
- * concurrently (the next frame fills the GPU while the last pixels of the
- * previous one finish) and accumulated in frame order.  At most two frames are
- * in flight: a third call waits on the host for the oldest to finish, so a
- * loop that never calls rt_sync cannot run ahead of the GPU.
+ * fire-and-forget submit.  A frame is launched at once while fewer than two
+ * launches are in flight; frames submitted while the GPU is busy with earlier
+ * ones are traced concurrently with them (up to three on side streams) or, in a
+ * loop that runs ahead of the GPU, held back and launched together as one batch
+ * (consecutive frame indices, otherwise equal uniforms; at most
+ * RT_TUNE_COALESCE_FRAMES of them, then the call waits on the host for the
+ * older launch, so such a loop cannot run ahead without bound).  Frames are
+ * accumulated in frame order, and every other entry point first launches what
+ * is held back: the effects of the calls are those of launching each frame in
+ * its own call.  An error in a held-back launch is reported by the call that
+ * launches it.
  */
 int rt_render_frame(rt_context *ctx);
 

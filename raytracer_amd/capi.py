@@ -20,6 +20,7 @@ RT_MODE_BVH_TILES = 2
 RT_TUNE_SHADE_NUM, RT_TUNE_LEAF_LANES, RT_TUNE_BLOCKS_PER_CU, RT_TUNE_BATCH_FRAMES, RT_TUNE_SHADOW_DONE_LANES = 0, 1, 2, 3, 4
 RT_TUNE_REFILL_LANES = 5
 RT_TUNE_MAX_STACK = 11
+RT_TUNE_COALESCE_FRAMES = 12
 RT_TUNE_MAX_LEAF, RT_TUNE_TRI_COST_X10, RT_TUNE_LDS_STATE, RT_TUNE_OVERLAP_FRAMES, RT_TUNE_SHADE_WAIT = 6, 7, 8, 9, 10
 
 # name -> (restype, argtypes); must list every symbol include/rt_hip.h declares

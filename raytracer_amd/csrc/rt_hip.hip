@@ -614,15 +614,30 @@ struct rt_context {
     // frame's trace fills the CUs the previous one leaves idle while its last pixels finish; each
     // has a staging slot for the frame colours and ids, and the accumulate step stays on `stream`,
     // in frame order.
-    hipStream_t aux[2] = {nullptr, nullptr};
-    hipEvent_t trace_done[2] = {nullptr, nullptr}, slot_free[2] = {nullptr, nullptr};
-    uint2 *d_slot[2] = {nullptr, nullptr};
-    int32_t *d_slot_ids[2] = {nullptr, nullptr};
-    bool slot_used[2] = {false, false};
-    int32_t *d_spill[3] = {nullptr, nullptr, nullptr}; // traversal stack overflow, per stream (main, side 0, side 1)
-    size_t spill_bytes[3] = {0, 0, 0};
+    static constexpr int kMaxSlots = 4;
+    hipStream_t aux[kMaxSlots] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t trace_done[kMaxSlots] = {nullptr, nullptr, nullptr, nullptr}, slot_free[kMaxSlots] = {nullptr, nullptr, nullptr, nullptr};
+    uint2 *d_slot[kMaxSlots] = {nullptr, nullptr, nullptr, nullptr};
+    int32_t *d_slot_ids[kMaxSlots] = {nullptr, nullptr, nullptr, nullptr};
+    bool slot_used[kMaxSlots] = {false, false, false, false};
+    int32_t *d_spill[1 + kMaxSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // traversal stack overflow, per stream (main, side streams)
+    size_t spill_bytes[1 + kMaxSlots] = {0, 0, 0, 0, 0};
     int next_slot = 0;
-    int tune_overlap = 1;
+    // Submission coalescing of rt_render_frame (see flush_pending): frames pending_first ..
+    // pending_first + pending_n - 1 have been asked for and not launched yet.
+    uint32_t pending_first = 0, pending_n = 0;
+    int tune_coalesce = 16;             // most frames held back; <= 1: every frame is launched by its own call
+    hipEvent_t flush_done[2] = {nullptr, nullptr}; // ends of the last two launches made by flush_pending
+    bool flush_used[2] = {false, false};
+    int next_flush = 0;
+    int tune_overlap = 3; // side streams (= frames in flight) of the single-frame path; 0: fused path on the main stream
+
+    int stream_index(hipStream_t s) const // 0 main, 1.. side streams
+    {
+        for (int k = 0; k < kMaxSlots; k++)
+            if (s == aux[k]) return 1 + k;
+        return 0;
+    }
     int tune_max_stack = 64;
     int tune_shade_wait = 12;
     bool sphere_lights = false; // opt-in extension: emissive spheres are sampled too (one-thread-per-pixel kernel)
@@ -682,7 +697,7 @@ int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchPar
     if (CFG::SPILL) {
         // one column of kSpillEntries per lane of the grid; launches that share it are serialised by their
         // streams only within a stream, so every stream (main, two side streams) has its own buffer
-        int which = stream == c->stream ? 0 : (stream == c->aux[0] ? 1 : 2);
+        int which = c->stream_index(stream);
         size_t need = (size_t)blocks * kBlock * kSpillEntries * sizeof(int32_t);
         if (c->spill_bytes[which] < need) {
             if (c->no_alloc)
@@ -696,7 +711,7 @@ int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchPar
             c->spill_bytes[which] = need;
         }
     }
-    int32_t *spill = CFG::SPILL ? c->d_spill[stream == c->stream ? 0 : (stream == c->aux[0] ? 1 : 2)] : nullptr;
+    int32_t *spill = CFG::SPILL ? c->d_spill[c->stream_index(stream)] : nullptr;
     // Starting a pixel (seed, jitter, camera ray) is long code: with few samples per pixel it runs
     // often, so more idle lanes are collected before a refill (measured optimum per spp).
     int refill = c->tune_refill_lanes;
@@ -744,9 +759,9 @@ int launch_persistent_d(rt_context *c, const rt::FrameParams &fp, const BatchPar
 // Side streams, events and staging slots of the overlapped single-frame path, made on first use.
 int ensure_slots(rt_context *c)
 {
-    if (c->aux[0]) return RT_OK;
     size_t local_px = (size_t)c->local_rows * c->width, px = (size_t)c->width * c->height;
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < c->tune_overlap && k < rt_context::kMaxSlots; k++) {
+        if (c->aux[k]) continue;
         RT_HIP_CHECK(hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
         RT_HIP_CHECK(hipEventCreateWithFlags(&c->trace_done[k], hipEventDisableTiming));
         RT_HIP_CHECK(hipEventCreateWithFlags(&c->slot_free[k], hipEventDisableTiming));
@@ -815,8 +830,8 @@ int launch_persistent(rt_context *c, uint32_t first, uint32_t n, uint32_t stride
         } else if (b == 1) {
             // one frame, traced on a side stream into a staging slot, accumulated on the main stream
             if ((rc = ensure_slots(c))) return rc;
-            int k = c->next_slot;
-            c->next_slot ^= 1;
+            int k = c->next_slot % c->tune_overlap;
+            c->next_slot = (k + 1) % c->tune_overlap;
             // The slot is free once the accumulate step of the frame before last has read it.  Waiting for
             // that on the host is the back-pressure of a render loop that never syncs: at most two
             // frames are in flight.
@@ -867,6 +882,49 @@ int check_ready(rt_context *c)
 }
 
 } // namespace
+
+static int render_frames_impl(rt_context *c, uint32_t first_frame_index, uint32_t n_frames, uint32_t stride, bool sum);
+
+// Submission coalescing.  rt_render_frame is the reference's fire-and-forget submit: one frame per
+// call, called back to back by a render loop.  A launch of one frame ends with a tail in which lanes
+// finish their last pixel while the others idle, so frames submitted while the GPU is still busy
+// with earlier ones are held back (up to tune_coalesce of them, consecutive frame indices, same
+// uniforms otherwise) and launched together as one batch, which is what rt_render_frames does.
+// Frames are launched at once while fewer than two launches are in flight, so a GPU that has
+// nothing to do never waits for a batch to fill.  Every other entry point launches what is pending
+// before it does anything else, so the order of effects is the order of the calls.
+static int flush_pending(rt_context *c)
+{
+    if (c->pending_n == 0) return RT_OK;
+    uint32_t first = c->pending_first, n = c->pending_n;
+    c->pending_n = 0;
+    int rc = render_frames_impl(c, first, n, 1, false);
+    if (rc) return rc;
+    int k = c->next_flush;
+    c->next_flush ^= 1;
+    if (!c->flush_done[k]) RT_HIP_CHECK(hipEventCreateWithFlags(&c->flush_done[k], hipEventDisableTiming));
+    RT_HIP_CHECK(hipEventRecord(c->flush_done[k], c->stream));
+    c->flush_used[k] = true;
+    return RT_OK;
+}
+
+// Launches made by flush_pending that have not finished yet (0..2).
+static int launches_in_flight(rt_context *c)
+{
+    int n = 0;
+    for (int k = 0; k < 2; k++)
+        if (c->flush_used[k]) {
+            if (hipEventQuery(c->flush_done[k]) == hipErrorNotReady) n++;
+            else c->flush_used[k] = false;
+        }
+    return n;
+}
+
+#define RT_FLUSH_PENDING(c)                     \
+    do {                                        \
+        int frc_ = flush_pending(c);            \
+        if (frc_) return frc_;                  \
+    } while (0)
 
 extern "C" {
 
@@ -935,12 +993,14 @@ void rt_destroy(rt_context *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->free_scene();
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < rt_context::kMaxSlots; k++) {
         if (c->aux[k]) { (void)hipStreamSynchronize(c->aux[k]); (void)hipStreamDestroy(c->aux[k]); }
         if (c->trace_done[k]) (void)hipEventDestroy(c->trace_done[k]);
         if (c->slot_free[k]) (void)hipEventDestroy(c->slot_free[k]);
         (void)hipFree(c->d_slot[k]); (void)hipFree(c->d_slot_ids[k]);
     }
+    for (hipEvent_t e : c->flush_done)
+        if (e) (void)hipEventDestroy(e);
     for (int32_t *p : c->d_spill) (void)hipFree(p);
     (void)hipFree(c->d_work); (void)hipFree(c->d_batch);
     (void)hipFree(c->fb.accum); (void)hipFree(c->fb.frame_f16); (void)hipFree(c->fb.ids); (void)hipFree(c->fb.counters);
@@ -997,6 +1057,7 @@ static float camera_magnitude(const rt_context *c)
 int rt_set_scene(rt_context *c, const void *spheres, uint32_t n_spheres, const void *triangles, uint32_t n_triangles)
 {
     if (!c) return fail(RT_ERR_INVALID, "null context");
+    RT_FLUSH_PENDING(c);
     if ((n_spheres && !spheres) || (n_triangles && !triangles)) return fail(RT_ERR_INVALID, "null scene buffer");
     if (n_triangles >= (1u << 28)) return fail(RT_ERR_UNSUPPORTED, "too many triangles");
     float cam = c->has_uniforms ? camera_magnitude(c) : 0.0f;
@@ -1026,6 +1087,14 @@ int rt_set_uniforms(rt_context *c, const void *uniforms80)
     if (!rt::make_frame_params(uniforms80, c->max_bounces, fp, err)) return fail(RT_ERR_INVALID, err);
     if (fp.width != c->width || fp.height != c->height)
         return fail(RT_ERR_INVALID, "uniforms.resolution differs from the context's width/height");
+    if (c->pending_n) {
+        // frames held back were asked for with the stored uniforms: they can stay pending only if
+        // nothing but frameIndex changes
+        float u[20];
+        std::memcpy(u, uniforms80, 80);
+        u[12] = c->uniforms[12];
+        if (std::memcmp(u, c->uniforms, 80) != 0) RT_FLUSH_PENDING(c);
+    }
     std::memcpy(c->uniforms, uniforms80, 80);
     c->has_uniforms = true;
     return RT_OK;
@@ -1034,6 +1103,7 @@ int rt_set_uniforms(rt_context *c, const void *uniforms80)
 int rt_set_max_bounces(rt_context *c, uint32_t max_bounces)
 {
     if (!c) return fail(RT_ERR_INVALID, "null context");
+    RT_FLUSH_PENDING(c);
     if (max_bounces > 255u) return fail(RT_ERR_INVALID, "max_bounces must be at most 255");
     c->max_bounces = max_bounces;
     return RT_OK;
@@ -1042,6 +1112,7 @@ int rt_set_max_bounces(rt_context *c, uint32_t max_bounces)
 int rt_set_sphere_lights(rt_context *c, int enable)
 {
     if (!c) return fail(RT_ERR_INVALID, "null context");
+    RT_FLUSH_PENDING(c);
     c->sphere_lights = enable != 0;
     return RT_OK;
 }
@@ -1049,6 +1120,7 @@ int rt_set_sphere_lights(rt_context *c, int enable)
 int rt_set_mode(rt_context *c, int mode)
 {
     if (!c) return fail(RT_ERR_INVALID, "null context");
+    RT_FLUSH_PENDING(c);
     if (mode != RT_MODE_BVH && mode != RT_MODE_BRUTE_FORCE && mode != RT_MODE_BVH_TILES) return fail(RT_ERR_INVALID, "unknown mode");
     c->mode = mode;
     return RT_OK;
@@ -1057,6 +1129,7 @@ int rt_set_mode(rt_context *c, int mode)
 int rt_set_tuning(rt_context *c, int key, int value)
 {
     if (!c) return fail(RT_ERR_INVALID, "null context");
+    RT_FLUSH_PENDING(c);
     switch (key) {
     case RT_TUNE_SHADE_NUM: if (value < 0 || value > 8) return fail(RT_ERR_INVALID, "shade_num out of range"); c->tune_shade_num = value; break;
     case RT_TUNE_LEAF_LANES: if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "leaf_lanes out of range"); c->tune_leaf_lanes = value; break;
@@ -1065,9 +1138,16 @@ int rt_set_tuning(rt_context *c, int key, int value)
     case RT_TUNE_MAX_LEAF: if (value < 1 || value > 8) return fail(RT_ERR_INVALID, "max_leaf out of range"); c->tune_max_leaf = value; break;
     case RT_TUNE_TRI_COST_X10: if (value < 1 || value > 1000) return fail(RT_ERR_INVALID, "tri_cost out of range"); c->tune_tri_cost_x10 = value; break;
     case RT_TUNE_REFILL_LANES: if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "refill_lanes out of range"); c->tune_refill_lanes = value; break;
-    case RT_TUNE_OVERLAP_FRAMES: if (value < 0 || value > 1) return fail(RT_ERR_INVALID, "overlap_frames out of range"); c->tune_overlap = value; break;
+    case RT_TUNE_OVERLAP_FRAMES:
+        if (value < 0 || value > rt_context::kMaxSlots) return fail(RT_ERR_INVALID, "overlap_frames out of range");
+        // frames still in flight on side streams that the new setting would no longer wait for
+        RT_HIP_CHECK(hipSetDevice(c->device));
+        RT_HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->tune_overlap = value == 1 ? 2 : value; // 1 = the original two side streams
+        break;
     case RT_TUNE_SHADE_WAIT: if (value < 0 || value > 1000) return fail(RT_ERR_INVALID, "shade_wait out of range"); c->tune_shade_wait = value; break;
     case RT_TUNE_LDS_STATE: if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "lds_state out of range"); c->tune_lds_state = value; break;
+    case RT_TUNE_COALESCE_FRAMES: if (value < 0 || value > 256) return fail(RT_ERR_INVALID, "coalesce_frames out of range"); c->tune_coalesce = value; break;
     case RT_TUNE_MAX_STACK: if (value < 1 || value > (int)kMaxStackEntries) return fail(RT_ERR_INVALID, "max_stack out of range"); c->tune_max_stack = value; break;
     case RT_TUNE_SHADOW_DONE_LANES: if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "shadow_done_lanes out of range"); c->tune_sdone_lanes = value; break;
     default: return fail(RT_ERR_INVALID, "unknown tuning key");
@@ -1104,6 +1184,8 @@ static int render_frames_impl(rt_context *c, uint32_t first_frame_index, uint32_
 
 int rt_render_frames(rt_context *c, uint32_t first_frame_index, uint32_t n_frames)
 {
+    if (!c) return fail(RT_ERR_INVALID, "null context");
+    RT_FLUSH_PENDING(c);
     return render_frames_impl(c, first_frame_index, n_frames, 1, false);
 }
 
@@ -1111,19 +1193,23 @@ int rt_render_frames_noalloc(rt_context *c, uint32_t first_frame_index, uint32_t
 {
     if (!c) return fail(RT_ERR_INVALID, "null context");
     c->no_alloc = true;
-    int rc = render_frames_impl(c, first_frame_index, n_frames, 1, false);
+    int rc = flush_pending(c); // frames held back by rt_render_frame go first, through the same workspace
+    if (!rc) rc = render_frames_impl(c, first_frame_index, n_frames, 1, false);
     c->no_alloc = false;
     return rc;
 }
 
 int rt_render_frame_sums(rt_context *c, uint32_t first_frame_index, uint32_t n_frames, uint32_t stride)
 {
+    if (!c) return fail(RT_ERR_INVALID, "null context");
+    RT_FLUSH_PENDING(c);
     return render_frames_impl(c, first_frame_index, n_frames, stride, true);
 }
 
 int rt_clear_accum(rt_context *c)
 {
     if (!c) return fail(RT_ERR_INVALID, "null context");
+    RT_FLUSH_PENDING(c);
     RT_HIP_CHECK(hipSetDevice(c->device));
     RT_HIP_CHECK(hipMemsetAsync(c->fb.accum, 0, (size_t)c->width * c->height * 3 * sizeof(float), c->stream));
     return RT_OK;
@@ -1132,6 +1218,7 @@ int rt_clear_accum(rt_context *c)
 int rt_export_accum(rt_context *c, void *dst_device)
 {
     if (!c || !dst_device) return fail(RT_ERR_INVALID, "null argument");
+    RT_FLUSH_PENDING(c);
     RT_HIP_CHECK(hipSetDevice(c->device));
     RT_HIP_CHECK(hipMemcpyAsync(dst_device, c->fb.accum, (size_t)c->width * c->height * 3 * sizeof(float),
                                 hipMemcpyDeviceToDevice, c->stream));
@@ -1141,6 +1228,7 @@ int rt_export_accum(rt_context *c, void *dst_device)
 int rt_import_accum(rt_context *c, const void *src_device)
 {
     if (!c || !src_device) return fail(RT_ERR_INVALID, "null argument");
+    RT_FLUSH_PENDING(c);
     RT_HIP_CHECK(hipSetDevice(c->device));
     RT_HIP_CHECK(hipMemcpyAsync(c->fb.accum, src_device, (size_t)c->width * c->height * 3 * sizeof(float),
                                 hipMemcpyDeviceToDevice, c->stream));
@@ -1150,6 +1238,7 @@ int rt_import_accum(rt_context *c, const void *src_device)
 int rt_finish_frame_sums(rt_context *c, uint32_t n_frames_total)
 {
     if (!c) return fail(RT_ERR_INVALID, "null context");
+    RT_FLUSH_PENDING(c);
     RT_HIP_CHECK(hipSetDevice(c->device));
     size_t n = (size_t)c->width * c->height * 3;
     hipLaunchKernelGGL(finish_sums_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->fb.accum, n,
@@ -1162,12 +1251,34 @@ int rt_render_frame(rt_context *c)
 {
     int rc = check_ready(c);
     if (rc) return rc;
-    return rt_render_frames(c, (uint32_t)c->uniforms[12], 1);
+    uint32_t frame = (uint32_t)c->uniforms[12];
+    bool coalesce = c->tune_coalesce > 1 && c->mode == RT_MODE_BVH && !c->sphere_lights && !c->counting &&
+                    persistent_stack_need(c) <= (uint32_t)c->tune_max_stack;
+    if (!coalesce) {
+        RT_FLUSH_PENDING(c);
+        return render_frames_impl(c, frame, 1, 1, false);
+    }
+    if (c->pending_n && frame != c->pending_first + c->pending_n) RT_FLUSH_PENDING(c);
+    if (c->pending_n == 0) c->pending_first = frame;
+    c->pending_n++;
+    // Launch now if the GPU would otherwise run dry (fewer than two launches in flight); hold the frame
+    // back otherwise, up to tune_coalesce frames, then wait for the older launch (the back-pressure of a
+    // render loop that never syncs) and launch them as one batch.
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    int busy = launches_in_flight(c);
+    if (busy >= 2 && c->pending_n >= (uint32_t)c->tune_coalesce) {
+        int older = c->next_flush; // the slot flush_pending records into next holds the older launch
+        if (c->flush_used[older]) RT_HIP_CHECK(hipEventSynchronize(c->flush_done[older]));
+        busy = launches_in_flight(c);
+    }
+    if (busy < 2) RT_FLUSH_PENDING(c);
+    return RT_OK;
 }
 
 int rt_sync(rt_context *c)
 {
     if (!c) return fail(RT_ERR_INVALID, "null context");
+    RT_FLUSH_PENDING(c);
     RT_HIP_CHECK(hipSetDevice(c->device));
     RT_HIP_CHECK(hipStreamSynchronize(c->stream));
     return RT_OK;
@@ -1176,6 +1287,7 @@ int rt_sync(rt_context *c)
 int rt_last_render_ms(rt_context *c, float *ms)
 {
     if (!c || !ms) return fail(RT_ERR_INVALID, "null argument");
+    RT_FLUSH_PENDING(c);
     if (!c->timed) return fail(RT_ERR_INVALID, "nothing rendered yet");
     RT_HIP_CHECK(hipSetDevice(c->device));
     RT_HIP_CHECK(hipEventSynchronize(c->ev_stop));
@@ -1186,6 +1298,7 @@ int rt_last_render_ms(rt_context *c, float *ms)
 int rt_read_accum(rt_context *c, float *rgb)
 {
     if (!c || !rgb) return fail(RT_ERR_INVALID, "null argument");
+    RT_FLUSH_PENDING(c);
     RT_HIP_CHECK(hipSetDevice(c->device));
     size_t px = (size_t)c->width * c->height;
     std::vector<float> planes(px * 3);
@@ -1202,6 +1315,7 @@ int rt_read_accum(rt_context *c, float *rgb)
 int rt_read_frame_f16(rt_context *c, uint16_t *rgba)
 {
     if (!c || !rgba) return fail(RT_ERR_INVALID, "null argument");
+    RT_FLUSH_PENDING(c);
     RT_HIP_CHECK(hipSetDevice(c->device));
     size_t px = (size_t)c->width * c->height;
     RT_HIP_CHECK(hipMemcpyAsync(rgba, c->fb.frame_f16, px * 4 * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
@@ -1212,6 +1326,7 @@ int rt_read_frame_f16(rt_context *c, uint16_t *rgba)
 int rt_read_primary_ids(rt_context *c, int32_t *ids)
 {
     if (!c || !ids) return fail(RT_ERR_INVALID, "null argument");
+    RT_FLUSH_PENDING(c);
     RT_HIP_CHECK(hipSetDevice(c->device));
     size_t px = (size_t)c->width * c->height;
     RT_HIP_CHECK(hipMemcpyAsync(ids, c->fb.ids, px * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1222,6 +1337,7 @@ int rt_read_primary_ids(rt_context *c, int32_t *ids)
 int rt_set_counting(rt_context *c, int enable)
 {
     if (!c) return fail(RT_ERR_INVALID, "null context");
+    RT_FLUSH_PENDING(c);
     c->counting = enable != 0;
     return RT_OK;
 }
@@ -1233,6 +1349,7 @@ int rt_set_counting(rt_context *c, int enable)
 int rt_debug_phase_cycles(rt_context *c, uint64_t out[16])
 {
     if (!c || !out) return fail(RT_ERR_INVALID, "null argument");
+    RT_FLUSH_PENDING(c);
     RT_HIP_CHECK(hipSetDevice(c->device));
     unsigned long long tmp[16];
     RT_HIP_CHECK(hipMemcpyAsync(tmp, c->fb.counters + 16, sizeof tmp, hipMemcpyDeviceToHost, c->stream));
@@ -1244,6 +1361,7 @@ int rt_debug_phase_cycles(rt_context *c, uint64_t out[16])
 int rt_read_counters(rt_context *c, uint64_t counters[16])
 {
     if (!c || !counters) return fail(RT_ERR_INVALID, "null argument");
+    RT_FLUSH_PENDING(c);
     RT_HIP_CHECK(hipSetDevice(c->device));
     unsigned long long tmp[16];
     RT_HIP_CHECK(hipMemcpyAsync(tmp, c->fb.counters, sizeof tmp, hipMemcpyDeviceToHost, c->stream));
@@ -1274,6 +1392,7 @@ int rt_owned_rows(rt_context *c, int *rows)
 int rt_export_owned_rows(rt_context *c, void *dst_device)
 {
     if (!c || !dst_device) return fail(RT_ERR_INVALID, "null argument");
+    RT_FLUSH_PENDING(c);
     RT_HIP_CHECK(hipSetDevice(c->device));
     size_t n = (size_t)c->local_rows * c->width;
     if (n == 0) return RT_OK;
@@ -1286,6 +1405,7 @@ int rt_export_owned_rows(rt_context *c, void *dst_device)
 int rt_import_rows(rt_context *c, const void *src_device, int from_index)
 {
     if (!c || !src_device) return fail(RT_ERR_INVALID, "null argument");
+    RT_FLUSH_PENDING(c);
     if (from_index < 0 || from_index >= c->sm.count) return fail(RT_ERR_INVALID, "from_index out of range");
     RT_HIP_CHECK(hipSetDevice(c->device));
     StripeMap sm = c->sm;

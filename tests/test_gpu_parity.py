@@ -454,3 +454,50 @@ def test_tree_deeper_than_the_accepted_stack_goes_to_the_tile_kernel(scenes):
     one-thread-per-pixel kernel instead of failing, single frames and batches alike."""
     run_pair(scenes["suzanne"], 100, 61, 2, 3, capi.RT_MODE_BVH, tuning=((capi.RT_TUNE_MAX_STACK, 4),))
     run_batched(scenes["suzanne"], 100, 61, 3, 2, 2, tuning=((capi.RT_TUNE_MAX_STACK, 4),))
+
+
+@pytest.mark.parametrize("coalesce", [0, 3, 16])
+def test_single_frame_submissions_are_coalesced_without_changing_results(scenes, coalesce):
+    """rt_render_frame in a loop that never waits: frames submitted while the GPU is busy are held back
+    and launched as batches.  The camera moves and the sample count changes half way (held-back frames
+    must be launched with the uniforms they were asked for), the frame index jumps once, a counter
+    read and a batch call come in between; everything must equal the frame-by-frame oracle."""
+    import copy
+
+    scene = scenes["suzanne"]
+    width, height = 160, 90
+    cam2 = copy.deepcopy(scene.camera)
+    cam2["position"] = [0.4, 2.6, 4.5]
+    cam2["rotation"] = [-8.0, 6.0, 0.0]
+    scene2 = S.Scene(camera=cam2, spheres=scene.spheres, triangles=scene.triangles)
+    ctx = capi.Context(width, height)
+    ctx.set_tuning(capi.RT_TUNE_COALESCE_FRAMES, coalesce)
+    ctx.set_scene(S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles))
+    orc = O.OracleRenderer(scene, width, height)
+    plan = [(scene, 2, f) for f in range(1, 24)] + [(scene2, 3, f) for f in range(24, 40)] + [(scene2, 3, f) for f in range(100, 108)]
+    taken = 0
+    for sc, spp, f in plan:
+        ctx.set_uniforms(S.pack_uniforms(sc.camera, f, width, height, spp))
+        ctx.render_frame()
+        orc.scene, orc.frame_index = sc, f - 1
+        orc.set_samples_per_pixel(spp)
+        orc.render()
+        if f == 11:
+            taken += ctx.take_triangle_tests()
+    assert np.array_equal(ctx.read_primary_ids(), orc.ids)
+    assert _f16_equal(ctx.read_frame_f16(), orc.frame_f16)
+    assert np.array_equal(ctx.read_accum(), orc.accum_rgb())
+    assert int(ctx.read_counters()[0]) == int(orc.counters[0])
+    assert (taken + ctx.take_triangle_tests()) % 2**32 == (int(orc.counters[0]) * 982) % 2**32
+    # held-back frames, then a batch call, then single frames again
+    for f in (108, 109):
+        ctx.set_uniforms(S.pack_uniforms(scene2.camera, f, width, height, 3))
+        ctx.render_frame()
+    ctx.render_frames(110, 3)
+    ctx.set_uniforms(S.pack_uniforms(scene2.camera, 113, width, height, 3))
+    ctx.render_frame()
+    orc.frame_index = 107
+    orc.render_frames(6)
+    assert np.array_equal(ctx.read_accum(), orc.accum_rgb())
+    assert np.array_equal(ctx.read_primary_ids(), orc.ids)
+    ctx.close()
