@@ -1,26 +1,37 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Mrays/s and ms/frame of the HIP path tracer on
-scene_suzanne.json at 1920x1080, 16 spp per frame (BASELINE.json configs[2]).
+"""Headline benchmark: Mrays/s and ms/frame of the HIP path tracer.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c]
 
 A step is one frame: one pass of the path-trace + accumulate hot path over the
-image at 16 samples per pixel.  K timed steps (default 16 = 256 spp, the
-configuration the metric is quoted on).
+image at 16 samples per pixel.  The default configuration is the one the metric
+is quoted on, BASELINE.json configs[2]: scene_suzanne.json at 1920x1080, K = 16
+timed frames = 256 spp.  ``--config`` selects another BASELINE configuration:
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the image rows are
-dealt to the ranks in 8-row stripes; each rank renders K*N frames of its
-stripes (so the work per GPU is that of the N = 1 run: weak scaling), no
+    a  scene_spheres 640x360                      (configs[0])
+    b  scene_boxes 1920x1080                      (configs[1])
+    c  scene_suzanne 1920x1080                    (configs[2], default)
+    d  scene_suzanne 3840x2160, rows split        (configs[3])
+    e  suzanne split 5x (991,246 triangles), 8 bounces, 1920x1080, frames split   (configs[4])
+    e_visible  the same mesh with the whole scene scaled x32, so that its triangles pass the
+       shader's determinant threshold and are actually seen (secondary line to e)
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): by default the image
+rows are dealt to the ranks in 8-row stripes; each rank renders K*N frames of
+its stripes (so the work per GPU is that of the N = 1 run: weak scaling), no
 collective on the data path, and one RCCL all-gather of the accumulator rows
 at the end, inside the timed region.  The assembled image is bit-identical to
-what one GPU renders for the same K*N frames.  ``--split frames`` deals the K*N
-frames instead (every rank renders whole images and sums them; one RCCL
-all-reduce of the sums at the end): same work per GPU, not bit-identical.
+what one GPU renders for the same K*N frames.  ``--split frames`` (the default
+of config e) deals the K*N frames instead (every rank renders whole images and
+sums them; one RCCL all-reduce of the sums at the end): same work per GPU, not
+bit-identical.
 
 Rank 0 prints one JSON line.  ``roofline`` prices the path-trace kernel against
-the FP32 vector peak (this path has no matrix work); ``cpu_baseline`` times the
-CPU oracle (a plain-C restatement of the reference shader) on a bounded band
-of the same frame.
+the FP32 vector peak (this path has no matrix work); the per-ray test counts and
+the lane utilisation behind it come from an instrumented launch of the same
+shape as the timed one (same frames per launch).  ``cpu_baseline`` times the CPU
+oracle (a plain-C restatement of the reference shader) on a bounded rectangle of
+the same frame.
 """
 import argparse
 import json
@@ -33,11 +44,21 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-SCENE = "suzanne"
-WIDTH, HEIGHT, SPP, MAX_BOUNCES = 1920, 1080, 16, 6
+SPP = 16
 PEAK_FP32_TFLOPS = 157.3  # MI355X FP32 vector peak (packed FMA), chip-level spec
 # algorithmic flop prices per test / per bounce ("Roofline accounting")
 F_BOX, F_TRI, F_SPH, F_SHADE = 24, 52, 31, 160
+
+CONFIGS = {
+    # name: (scene, width, height, max bounces, default split, what BASELINE.json calls it)
+    "a": ("spheres", 640, 360, 6, "rows", "scene_spheres.json 640x360"),
+    "b": ("boxes", 1920, 1080, 6, "rows", "scene_boxes.json 1920x1080"),
+    "c": ("suzanne", 1920, 1080, 6, "rows", "scene_suzanne.json 1920x1080"),
+    "d": ("suzanne", 3840, 2160, 6, "rows", "scene_suzanne.json 3840x2160"),
+    "e": ("suzanne_x5", 1920, 1080, 8, "frames", "suzanne model split 5x (991,246 triangles) 1920x1080"),
+    "e_visible": ("suzanne_x5_scaled", 1920, 1080, 8, "frames",
+                  "suzanne model split 5x (991,246 triangles), scene scaled x32 (mesh visible) 1920x1080"),
+}
 
 
 def parse_args():
@@ -45,39 +66,72 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU baseline band (0 = auto)")
-    ap.add_argument("--split", choices=["rows", "frames"], default="rows",
-                    help="N > 1: deal image rows (exact, default) or frames (sums + all-reduce) to the ranks")
+    ap.add_argument("--split", choices=["rows", "frames"], default=None,
+                    help="N > 1: deal image rows (exact) or frames (sums + all-reduce) to the ranks; default by config")
     return ap.parse_args()
 
 
-def cpu_baseline(scene, threads):
-    """Times the CPU oracle on a band of frame 1 (same scene, resolution, spp)."""
+def load_config_scene(name):
+    """(camera, packed spheres, packed triangles, description of the data)"""
+    from raytracer_amd import scene as S
+
+    if name == "suzanne_x5":
+        cam, sp, tr = S.subdivided_suzanne_packed(5)
+        return cam, sp, tr, "scene_suzanne.json with its model's triangles split at the edge midpoints 5 times (deterministic)"
+    if name == "suzanne_x5_scaled":
+        cam, sp, tr = S.subdivided_suzanne_packed(5, 32.0)
+        return cam, sp, tr, "scene_suzanne.json, model split 5 times, every coordinate scaled x32 (deterministic)"
+    scene = S.load_scene(S.scene_path(name))
+    return (scene.camera, S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles),
+            "reference scene file scene_%s.json%s (%d triangles, %d spheres); no random inputs"
+            % (name, " + models/suzanne_500_tris.obj" if name == "suzanne" else "", len(scene.triangles), len(scene.spheres)))
+
+
+def cpu_baseline(camera, spheres, tris, width, height, max_bounces, threads):
+    """Times the CPU oracle on a rectangle of frame 1 (same scene, resolution, spp), sized for
+    about 15 s of CPU work."""
     from tests import oracle_lib as O
 
-    def run(y0, y1):
-        orc = O.OracleRenderer(scene, WIDTH, HEIGHT, max_bounces=MAX_BOUNCES, threads=threads, rect=(0, y0, WIDTH, y1))
+    def run(x0, y0, x1, y1):
+        orc = O.OracleRenderer((camera, spheres, tris), width, height, max_bounces=max_bounces, threads=threads,
+                               rect=(x0, y0, x1, y1))
         orc.set_samples_per_pixel(SPP)
         t = time.perf_counter()
         orc.render()
         return int(orc.counters[0]), time.perf_counter() - t
 
-    # warm up (library load, thread start), calibrate on one row per thread (the oracle splits a band
-    # into rows), then size the band for about 15 s
-    run(540, 541)
-    cal = max(2, min(threads, 64))
-    rays, dt = run(540 - cal // 2, 540 - cal // 2 + cal)
-    rows = int(max(cal, min(HEIGHT // 2, round(cal * 15.0 / max(dt, 1e-3)))))
-    y0 = (HEIGHT - rows) // 2
-    rays, dt = run(y0, y0 + rows)
+    cy, cx = height // 2, width // 2
+    # warm up (library load, thread start), then calibrate on one pixel per thread (the oracle splits a
+    # rectangle into rows, one row per thread at a time); if that is too short to time, on one row per thread
+    run(cx, cy, cx + 1, cy + 1)
+    cal = max(2, min(threads, 64, height))
+    y0 = cy - cal // 2
+    rays, dt = run(cx, y0, cx + 1, y0 + cal)
+    cal_pixels = cal
+    if dt < 0.2:
+        rays, dt = run(0, y0, width, y0 + cal)
+        cal_pixels = cal * width
+    pixels = max(cal, int(round(cal_pixels * 15.0 / max(dt, 1e-3))))
+    # a rectangle of about that many pixels around the centre: whole rows if it takes more than one row per thread
+    if pixels >= width * cal:
+        rows = max(cal, min(height // 2, pixels // width))
+        x0, x1 = 0, width
+    else:
+        rows = cal
+        w = max(1, min(width, pixels // rows))
+        x0, x1 = (width - w) // 2, (width - w) // 2 + w
+    y0 = (height - rows) // 2
+    y1 = y0 + rows
+    rays, dt = run(x0, y0, x1, y1)
     return {
         "value": rays / dt / 1e6,
         "unit": "Mrays/s",
         "cores": threads,
         "kind": "port",
-        "sample": "rows %d..%d of frame 1 (%d of %d pixels), %d spp, %d rays in %.1f s"
-                  % (y0, y0 + rows, rows * WIDTH, WIDTH * HEIGHT, SPP, rays, dt),
+        "sample": "pixels x %d..%d, y %d..%d of frame 1 (%d of %d pixels), %d spp, %d rays in %.1f s"
+                  % (x0, x1, y0, y1, (x1 - x0) * (y1 - y0), width * height, SPP, rays, dt),
     }
 
 
@@ -88,6 +142,9 @@ def main():
 
     from raytracer_amd import capi
     from raytracer_amd import scene as S
+
+    scene_name, WIDTH, HEIGHT, MAX_BOUNCES, default_split, label = CONFIGS[args.config]
+    split = args.split or default_split
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -117,16 +174,22 @@ def main():
 
     from raytracer_amd import sharding
 
-    scene = S.load_scene(S.scene_path(SCENE))
-    spheres, tris = S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles)
-    by_frames = args.split == "frames" and use_dist
-    if by_frames:
-        ctx = capi.Context(WIDTH, HEIGHT, device=device)
-    else:
-        ctx = capi.Context(WIDTH, HEIGHT, device=device, stripe_rows=8, stripe_index=rank, stripe_count=world)
-    ctx.set_max_bounces(MAX_BOUNCES)
-    ctx.set_scene(spheres, tris)
-    ctx.set_uniforms(S.pack_uniforms(scene.camera, 1, WIDTH, HEIGHT, SPP))
+    camera, spheres, tris, data_note = load_config_scene(scene_name)
+    by_frames = split == "frames" and use_dist
+
+    def new_context(stripe=True):
+        if by_frames or not stripe:
+            c = capi.Context(WIDTH, HEIGHT, device=device)
+        else:
+            c = capi.Context(WIDTH, HEIGHT, device=device, stripe_rows=8, stripe_index=rank, stripe_count=world)
+        c.set_max_bounces(MAX_BOUNCES)
+        c.set_uniforms(S.pack_uniforms(camera, 1, WIDTH, HEIGHT, SPP))   # before the scene: the camera's distance sizes the boxes
+        t = time.perf_counter()
+        c.set_scene(spheres, tris)
+        c.sync()
+        return c, time.perf_counter() - t
+
+    ctx, scene_seconds = new_context()
 
     frames_per_step = world  # weak scaling: every rank keeps the N = 1 amount of work
     K, W = args.steps, args.warmup
@@ -140,7 +203,7 @@ def main():
     own = ctx.owned_rows()
     frames_per_launch = ctx.frames_per_launch()
     frames_this_rank = sharding.frames_of_rank(1, K * frames_per_step, rank, world)[1] if by_frames else K * frames_per_step
-    local_rows = torch.empty((3, own, WIDTH), dtype=torch.float32, device="cuda") if use_dist else None
+    local_rows = torch.empty((3, HEIGHT if by_frames else own, WIDTH), dtype=torch.float32, device="cuda") if use_dist else None
 
     # warmup (frames 1..W*frames_per_step); the timed run then restarts at frame 1
     if W > 0:
@@ -194,31 +257,24 @@ def main():
     if os.environ.get("RT_BENCH_VERBOSE") == "1":
         print("rank %d: %d rays traversed, kernel %.1f ms" % (rank, rays, kernel_ms), file=sys.stderr)
 
-    if world > 1 and rank == 0 and os.environ.get("RT_BENCH_VERIFY") == "1" and by_frames:
-        ref = capi.Context(WIDTH, HEIGHT, device=device)
-        ref.set_max_bounces(MAX_BOUNCES)
-        ref.set_scene(spheres, tris)
-        ref.set_uniforms(S.pack_uniforms(scene.camera, 1, WIDTH, HEIGHT, SPP))
-        ref.render_frames(1, K * frames_per_step)
-        a, b = ref.read_accum(), ctx.read_accum()
+    if world > 1 and rank == 0 and os.environ.get("RT_BENCH_VERIFY") == "1":
+        ref, _ = new_context(stripe=False)
+        if by_frames:
+            ref.render_frames(1, K * frames_per_step)
+            a, b = ref.read_accum(), ctx.read_accum()
+            d = np.abs(a - b)
+            print("verify: frame split vs single-GPU recurrence: %d of %d values differ by more than 1e-3 (clamped pixels), "
+                  "median abs diff %.3g" % (int((d > 1e-3).sum()), d.size, float(np.median(d))), file=sys.stderr)
+        else:
+            # the assembled image must equal what one GPU renders for the same frames (after the same warmup)
+            if W > 0:
+                ref.render_frames(1, W * frames_per_step)
+            ref.render_frames(1, K * frames_per_step)
+            same = bool(np.array_equal(ref.read_accum(), ctx.read_accum()))
+            print("verify: assembled image bit-identical to the single-GPU render: %s" % same, file=sys.stderr)
+            if not same:
+                raise SystemExit("verification failed")
         ref.close()
-        d = np.abs(a - b)
-        print("verify: frame split vs single-GPU recurrence: %d of %d values differ by more than 1e-3 (clamped pixels), "
-              "median abs diff %.3g" % (int((d > 1e-3).sum()), d.size, float(np.median(d))), file=sys.stderr)
-    elif world > 1 and rank == 0 and os.environ.get("RT_BENCH_VERIFY") == "1":
-        # the assembled image must equal what one GPU renders for the same frames (after the same warmup)
-        ref = capi.Context(WIDTH, HEIGHT, device=device)
-        ref.set_max_bounces(MAX_BOUNCES)
-        ref.set_scene(spheres, tris)
-        ref.set_uniforms(S.pack_uniforms(scene.camera, 1, WIDTH, HEIGHT, SPP))
-        if W > 0:
-            ref.render_frames(1, W * frames_per_step)
-        ref.render_frames(1, K * frames_per_step)
-        same = bool(np.array_equal(ref.read_accum(), ctx.read_accum()))
-        ref.close()
-        print("verify: assembled image bit-identical to the single-GPU render: %s" % same, file=sys.stderr)
-        if not same:
-            raise SystemExit("verification failed")
 
     t = torch.tensor([dt, float(rays), kernel_ms, float(ray_calls)], dtype=torch.float64, device="cpu" if rehearse else "cuda")
     if use_dist:
@@ -231,35 +287,61 @@ def main():
         dist.destroy_process_group()
         return
 
-    # roofline: algorithmic flops of the timed launches / HIP-event time of those launches
-    cctx = capi.Context(WIDTH, HEIGHT, device=device)
-    cctx.set_max_bounces(MAX_BOUNCES)
-    cctx.set_scene(spheres, tris)
-    cctx.set_counting(True)
-    cctx.set_uniforms(S.pack_uniforms(scene.camera, 1, WIDTH, HEIGHT, SPP))
-    cctx.render_frame()
-    cnt = [int(x) for x in cctx.read_counters()]
-    cctx.close()
-    c_rays, c_boxpairs, c_tris, c_sph, c_bounces = cnt[13], cnt[1], cnt[2], cnt[3], cnt[4]
-    lane_util = None
-    if cnt[5]:
-        lane_util = {"inner": cnt[6] / cnt[5] / 64, "triangle": cnt[8] / max(cnt[7], 1) / 64,
-                     "shade": cnt[10] / max(cnt[9], 1) / 64, "shadow_done": cnt[12] / max(cnt[11], 1) / 64}
-    flops_per_ray = (2 * c_boxpairs * F_BOX + c_tris * F_TRI + c_sph * F_SPH + c_bounces * F_SHADE) / c_rays
-    brute_flops_per_ray = F_SPH * len(spheres) + F_TRI * len(tris)
+    # roofline: algorithmic flops of the timed launches / HIP-event time of those launches.  The
+    # per-ray test counts and the lane utilisation come from an instrumented launch of the same
+    # shape as the timed ones: the same context geometry, the same frames, the same frames per launch.
     frames = K * frames_per_step
     batch = frames_per_launch       # frames per kernel launch, as chosen by the library for this context
     launches = max(1, (frames_this_rank + batch - 1) // batch)
+    counted_frames = min(frames_this_rank, batch) if frames_this_rank else 1
+    cctx, _ = new_context()
+    cctx.set_counting(True)
+    if by_frames:
+        cctx.clear_accum()
+        cctx.render_frame_sums(1 + rank, counted_frames, world)
+    else:
+        cctx.render_frames(1, counted_frames)
+    cnt = [int(x) for x in cctx.read_counters()]
+    cctx.close()
+    c_rays, c_boxpairs, c_tris, c_sph, c_bounces = max(cnt[13], 1), cnt[1], cnt[2], cnt[3], cnt[4]
+    lane_util = None
+    if cnt[5]:
+        lane_util = {"inner": cnt[6] / cnt[5] / 64, "triangle": cnt[8] / max(cnt[7], 1) / 64,
+                     "shade": cnt[10] / max(cnt[9], 1) / 64, "shadow_done": cnt[12] / max(cnt[11], 1) / 64,
+                     "frames_in_the_instrumented_launch": counted_frames}
+    flops_per_ray = (2 * c_boxpairs * F_BOX + c_tris * F_TRI + c_sph * F_SPH + c_bounces * F_SHADE) / c_rays
+    brute_flops_per_ray = F_SPH * len(spheres) + F_TRI * len(tris)
     rays_per_launch = rays / world / launches
     launch_ms = max(kernel_ms / launches, 1e-9)
     achieved = flops_per_ray * rays_per_launch / (launch_ms * 1e-3) / 1e12
-    traffic = None
+    # HBM traffic of the trace kernel: measured per frame by the PMC passes (profiles/, same configuration only),
+    # scaled to the frames of one timed launch; algorithmic bytes: one 8-byte rgba16float colour written per
+    # pixel-frame, the primary ids of the last frame (4 B per pixel), and the scene read once
+    frames_in_launch = min(frames_this_rank, batch) if frames_this_rank else 0
+    owned_px = (HEIGHT if by_frames else own) * WIDTH
+    algorithmic_bytes = frames_in_launch * owned_px * 8 + owned_px * 4 + ctx.scene_stats()["device_bytes"]
+    traffic, traffic_note = None, "no PMC measurement for this configuration in profiles/"
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
+    if os.path.exists(pmc) and world == 1:
         try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            rec = json.load(open(pmc)).get(args.config)
+            if rec:
+                traffic = rec["hbm_bytes_per_frame"] * frames_in_launch
+                traffic_note = rec.get("source", "")
         except Exception:
             traffic = None
+    valu = None
+    calib = os.path.join(ROOT, "profiles", "valu_calibration.json")
+    if os.path.exists(calib) and world == 1:
+        try:
+            rec = json.load(open(calib))
+            k = rec.get("kernel", {}).get(args.config)
+            if k:
+                valu = {"valu_insts_per_simd_cycle": k["valu_insts_per_simd_cycle"], "ceiling_plain_fma": rec["ceiling_plain_fma"],
+                        "frac_of_ceiling": k["valu_insts_per_simd_cycle"] / rec["ceiling_plain_fma"],
+                        "lanes_active_per_valu_inst": k["lanes_active_per_valu_inst"], "source": rec.get("source", "")}
+        except Exception:
+            valu = None
 
     out = {
         "metric": "Mrays/s",
@@ -273,18 +355,21 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "reference scene file scene_suzanne.json + models/suzanne_500_tris.obj (982 triangles, 1 sphere); no random inputs",
+        "data": data_note,
         "config": {
-            "workload": "scene_suzanne.json 1920x1080, %d frames x %d spp, max bounces %d, BVH traversal%s"
-                        % (K * frames_per_step, SPP, MAX_BOUNCES,
+            "workload": "%s, %d frames x %d spp, max bounces %d, BVH traversal%s"
+                        % (label, frames, SPP, MAX_BOUNCES,
                            "" if world == 1 else
                            (", frames dealt to %d GPUs + RCCL all-reduce of the sums" % world if by_frames else
                             ", rows dealt to %d GPUs in 8-row stripes + RCCL all-gather" % world)),
-            "frames": K * frames_per_step,
+            "baseline_config": args.config,
+            "frames": frames,
             "spp_per_frame": SPP,
-            "ms_per_frame": dt * 1e3 / max(K * frames_per_step, 1),
+            "ms_per_frame": dt * 1e3 / max(frames, 1),
             "rays": rays,
             "ray_all_calls_of_the_reference": ray_calls,
+            "triangles": int(len(tris)),
+            "scene_upload_and_build_s": scene_seconds,
             "note": "value counts rays actually traversed; the camera ray of a pixel is traversed once per frame and its "
                     "hit reused by the frame's 16 samples, which the shader starts on the same ray, so the reference's own "
                     "counter would read ray_all_calls_of_the_reference",
@@ -296,22 +381,26 @@ def main():
             "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_TFLOPS,
             "traffic": traffic,
+            "algorithmic_bytes": algorithmic_bytes,
+            "traffic_note": traffic_note,
             "kernel": "render_persistent_kernel (path trace of up to %d frames per launch; the ordered accumulate kernel "
                       "that follows it is included in the timing and is < 0.1%% of it)" % batch,
             "launches": launches,
+            "frames_per_launch": frames_in_launch,
             "kernel_ms_per_launch": launch_ms,
             "flops_per_ray": flops_per_ray,
             "rays_per_launch": rays_per_launch,
             "per_ray": {"box_tests": 2 * c_boxpairs / c_rays, "triangle_tests": c_tris / c_rays,
                         "sphere_tests": c_sph / c_rays, "bounces": c_bounces / c_rays},
             "lane_utilisation": lane_util,
+            "valu_issue": valu,
             "brute_force_equivalent": {"flops_per_ray": brute_flops_per_ray,
                                        "tflops": brute_flops_per_ray * rays_per_launch / (launch_ms * 1e-3) / 1e12},
         },
     }
     if world == 1 and not args.no_cpu_baseline:
         threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
-        out["cpu_baseline"] = cpu_baseline(scene, threads)
+        out["cpu_baseline"] = cpu_baseline(camera, spheres, tris, WIDTH, HEIGHT, MAX_BOUNCES, threads)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))

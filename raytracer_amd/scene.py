@@ -227,3 +227,43 @@ def scene_path(name: str) -> str:
     """``scene_path('suzanne')`` -> .../scene_suzanne.json"""
     fname = name if name.endswith(".json") else "scene_%s.json" % name
     return os.path.join(scene_dir(), fname)
+
+
+def subdivided_suzanne_packed(levels: int, scale: float = 1.0):
+    """scene_suzanne with the triangles of its OBJ model split at the edge midpoints
+    `levels` times (968 * 4**levels triangles; 991,232 at 5), as packed records:
+    returns (camera, spheres (n,16) float32, triangles (n,24) float32).  Room, light
+    and sphere are kept.  Midpoints are taken in float64 and rounded to float32 once.
+
+    With every split the triangles' determinant in ray_triangle_intersect shrinks by
+    4; from about the third level most of them fall under the reference's
+    abs(a) < 0.001 rejection (common.wgsl:179) and stop being visible, while they
+    are still tested: a traversal-cost workload more than a picture.  `scale`
+    multiplies every coordinate of the scene (geometry, sphere radius, camera
+    position): at 32 the five-times-split triangles are as large against that
+    threshold as the unsplit ones at 1, so the mesh is visible again and the
+    picture is the original one up to the shader's absolute offsets."""
+    import copy
+
+    base = load_scene(scene_path("suzanne"))
+    room = pack_triangles(base.triangles[:14])
+    model = pack_triangles(base.triangles[14:])
+    v = np.stack([model[:, 0:3], model[:, 4:7], model[:, 8:11]], axis=1).astype(np.float64)  # (n, 3 verts, 3)
+    for _ in range(levels):
+        a, b, c = v[:, 0], v[:, 1], v[:, 2]
+        ab, bc, ca = 0.5 * (a + b), 0.5 * (b + c), 0.5 * (c + a)
+        v = np.concatenate([np.stack([a, ab, ca], 1), np.stack([ab, b, bc], 1),
+                            np.stack([ca, bc, c], 1), np.stack([ab, bc, ca], 1)], axis=1).reshape(-1, 3, 3)
+    out = np.repeat(model[:1], len(v), axis=0)
+    out[:, 0:3], out[:, 4:7], out[:, 8:11] = v[:, 0], v[:, 1], v[:, 2]
+    tris = np.concatenate([room, out], axis=0)
+    spheres = pack_spheres(base.spheres)
+    camera = base.camera
+    if scale != 1.0:
+        k = np.float32(scale)
+        for c0 in (0, 4, 8):
+            tris[:, c0:c0 + 3] *= k
+        spheres[:, 0:4] *= k          # centre and radius
+        camera = copy.deepcopy(base.camera)
+        camera["position"] = [float(np.float32(x) * k) for x in camera["position"]]
+    return camera, spheres, tris

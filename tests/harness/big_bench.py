@@ -2,7 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from raytracer_amd import capi, scene as S
-from tests.synth import subdivided_suzanne_packed
+from raytracer_amd.scene import subdivided_suzanne_packed
 levels = int(sys.argv[1]) if len(sys.argv) > 1 else 5   # negative: height field of (-levels)^2 quads instead
 W, H, spp, frames = 1920, 1080, 16, int(sys.argv[2]) if len(sys.argv) > 2 else 4
 if levels < 0:

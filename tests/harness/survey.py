@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from raytracer_amd import capi, scene as S
 from tests.synth import heightfield_scene
-from tests.synth import subdivided_suzanne_packed
+from raytracer_amd.scene import subdivided_suzanne_packed
 def run(label, sc, W, H, frames, spp, bounces=6):
     ctx = capi.Context(W, H); ctx.set_max_bounces(bounces)
     cam, sp, tr = sc if isinstance(sc, tuple) else (sc.camera, S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles))

@@ -68,6 +68,10 @@ __global__ __launch_bounds__(256) void fma_kernel(float *out, unsigned long long
 int main(int argc, char **argv)
 {
     int iters = argc > 1 ? atoi(argv[1]) : 20000;
+    // optional filter, for runs under rocprofv3 --pmc: kind (fma | pk), mask number, waves per SIMD
+    int only_packed = argc > 2 ? (argv[2][0] == 'p' ? 1 : 0) : -1;
+    int only_mask = argc > 3 ? atoi(argv[3]) : -1;
+    int only_wps = argc > 4 ? atoi(argv[4]) : -1;
     int dev = 0;
     CHECK(hipSetDevice(dev));
     hipDeviceProp_t prop;
@@ -97,8 +101,12 @@ int main(int argc, char **argv)
     CHECK(hipEventCreate(&e1));
     printf("%-8s %-46s %5s %10s %12s %14s %14s\n", "kind", "mask", "w/SIMD", "ms", "wave-clk/FMA", "FMA/SIMD/clk", "lane-TFLOP/s");
     for (int packed = 0; packed < 2; packed++) {
-        for (const M &m : masks) {
+        if (only_packed >= 0 && packed != only_packed) continue;
+        for (size_t mi = 0; mi < masks.size(); mi++) {
+            if (only_mask >= 0 && (int)mi != only_mask) continue;
+            const M &m = masks[mi];
             for (int wps : {1, 2, 4, 8}) {
+                if (only_wps >= 0 && wps != only_wps) continue;
                 int blocks = cus * wps; // 256 threads = 4 waves = one wave per SIMD per block
                 // warm up, then time
                 for (int rep = 0; rep < 2; rep++) {

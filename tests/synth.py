@@ -33,28 +33,7 @@ def heightfield_scene(n: int, amplitude: float = 0.6) -> S.Scene:
     return S.Scene(camera=base.camera, spheres=base.spheres, triangles=tris)
 
 
-def subdivided_suzanne_packed(levels: int):
-    """scene_suzanne with the triangles of its OBJ model split at the edge midpoints
-    `levels` times (968 * 4**levels triangles; 991,232 at 5), as packed records:
-    returns (camera, spheres (n,16) float32, triangles (n,24) float32).  Room, light
-    and sphere are kept.  Midpoints are taken in float64 and rounded to float32 once.
-
-    With every split the triangles' determinant in ray_triangle_intersect shrinks by
-    4; from about the third level most of them fall under the reference's
-    abs(a) < 0.001 rejection (common.wgsl:179) and stop being visible, while they
-    are still tested: a traversal-cost workload more than a picture."""
-    base = S.load_scene(S.scene_path("suzanne"))
-    room = S.pack_triangles(base.triangles[:14])
-    model = S.pack_triangles(base.triangles[14:])
-    v = np.stack([model[:, 0:3], model[:, 4:7], model[:, 8:11]], axis=1).astype(np.float64)  # (n, 3 verts, 3)
-    for _ in range(levels):
-        a, b, c = v[:, 0], v[:, 1], v[:, 2]
-        ab, bc, ca = 0.5 * (a + b), 0.5 * (b + c), 0.5 * (c + a)
-        v = np.concatenate([np.stack([a, ab, ca], 1), np.stack([ab, b, bc], 1),
-                            np.stack([ca, bc, c], 1), np.stack([ab, bc, ca], 1)], axis=1).reshape(-1, 3, 3)
-    out = np.repeat(model[:1], len(v), axis=0)
-    out[:, 0:3], out[:, 4:7], out[:, 8:11] = v[:, 0], v[:, 1], v[:, 2]
-    return base.camera, S.pack_spheres(base.spheres), np.concatenate([room, out], axis=0)
+from raytracer_amd.scene import subdivided_suzanne_packed  # noqa: E402,F401  (the generator of BASELINE's synthetic configuration)
 
 
 def edge_scenes() -> dict:
