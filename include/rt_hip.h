@@ -170,7 +170,7 @@ int rt_render_frames(rt_context *ctx, uint32_t first_frame_index, uint32_t n_fra
  * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same
  * result as rt_render_frames, bit for bit, through the same kernels; the per-launch work counter
  * and the frame colours of a launch, which rt_render_frames keeps in buffers it allocates on
- * demand, live in a fixed 64 MiB + 256 B device array that is part of the library image (each GPU
+ * demand, live in a fixed 64 MiB + 512 B device array that is part of the library image (each GPU
  * the library runs on holds one until the process ends).  Calls no hipMalloc / hipFree.
  * Limits, reported as RT_ERR_UNSUPPORTED with a message:
  *   - the context may own at most 8,388,608 pixels (64 MiB / 8 B; a 3840x2160 image fits);

@@ -36,13 +36,13 @@ int fail(int code, const std::string &msg)
 
 // ---------------------------------------------------------------------------
 // Workspace of rt_render_frames_noalloc: a fixed device array, so that entry point never allocates.
-// Layout: [0, kScratchHeader) the work counter of the launch in flight; then the rgba16float
+// Layout: [0, kScratchHeader) the work counters of the launch in flight; then the rgba16float
 // colours of the frames of one launch (what rt_render_frames keeps in a hipMalloc'ed batch buffer).
 // Every GPU the library runs on holds its own copy of the array until the process ends.  In host
 // code the array's name is only a handle: its device address comes from hipGetSymbolAddress, once per
 // device (scratch_of), and only that pointer is ever passed to kernels and memsets.
 // ---------------------------------------------------------------------------
-constexpr size_t kScratchHeader = 256;
+constexpr size_t kScratchHeader = 512;
 constexpr size_t kScratchColorBytes = (size_t)64 << 20; // 8,388,608 pixel-frames: one 3840x2160 frame, four 1920x1080 frames
 static __device__ __align__(256) unsigned char scratch[kScratchHeader + kScratchColorBytes];
 
@@ -78,6 +78,9 @@ __host__ __device__ inline int stripe_global_row(const StripeMap &m, int local)
 // Per-lane traversal stack in LDS: entry k of lane l lives at base[k * BLOCK + l],
 // so one wave's pushes/pops touch 64 consecutive dwords (no bank conflicts).
 // ---------------------------------------------------------------------------
+#ifndef RT_XCC_ID_QUEUE
+#define RT_XCC_ID_QUEUE 0 // 1: a wave's first work queue is chosen by the XCC_ID hardware register instead of blockIdx % 8
+#endif
 #ifndef RT_LEAF_LOOP
 #define RT_LEAF_LOOP 0 // 1: a triangle step tests every triangle of the leaf, not only the next one
 #endif
@@ -203,6 +206,8 @@ __device__ inline void store_pixel(const rt::FrameParams &fp, const FrameBuffers
 // reference's @workgroup_size(8, 8); four tiles per 256-thread block.
 // ---------------------------------------------------------------------------
 constexpr int kBlock = 256;
+constexpr uint32_t kQueues = 8;       // work queues of a launch of the persistent kernel: one per XCD
+constexpr uint32_t kQueueStride = 16; // their counters are 64 bytes apart
 #ifndef RT_MINW
 #define RT_MINW 5 // waves per SIMD the persistent kernel is compiled for when lane state stays in registers (<= 96 VGPRs)
 #endif
@@ -306,7 +311,20 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
 
     const uint32_t tiles_x = (uint32_t)(fp.width + 7) / 8u, tiles_y = (uint32_t)(local_rows + 7) / 8u;
     const uint32_t tiles_per_frame = tiles_x * tiles_y;
-    const uint32_t total_units = tiles_per_frame * bp.n_frames * 64u;
+    // Work queues.  The (frame, pixel) units of a launch are split into kQueues queues, each with its
+    // own counter: queue q holds the q-th contiguous share of a frame's tiles (a band of the image),
+    // for all frames of the launch, frame-major.  A wave starts on the queue of its XCD (workgroups
+    // are dealt to the eight XCDs round-robin, so that is blockIdx % 8) and moves on to the next queue
+    // when its own runs out, until all are empty.  Each XCD has its own L2: as long as the queues
+    // last, the camera and shadow rays of an XCD stay within one band of the image, i.e. within one
+    // part of the scene, instead of every L2 holding the geometry behind the whole image.
+#if RT_XCC_ID_QUEUE
+    // the XCD the wave runs on, from the hardware register (HW_REG_XCC_ID = 20, bits 0..3)
+    uint32_t my_queue = (uint32_t)__builtin_amdgcn_s_getreg(20 | (3 << 11)) % kQueues;
+#else
+    uint32_t my_queue = blockIdx.x % kQueues; // wave-uniform
+#endif
+    uint32_t queues_left = 0;                  // queues this wave has found empty and left behind
 
     rt::Lane L;
     L.mode = rt::kLaneNeedUnit;
@@ -356,32 +374,37 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
             if (need != 0ull && exhausted) {
                 if (L.mode == rt::kLaneNeedUnit) L.mode = rt::kLaneDead;
             } else if (need != 0ull && (!any_busy || n_need >= (uint32_t)sched.refill_lanes)) {
+                // this queue's share of the tiles of a frame, and its length in units
+                const uint32_t q_first = (uint32_t)((uint64_t)tiles_per_frame * my_queue / kQueues);
+                const uint32_t q_tiles = (uint32_t)((uint64_t)tiles_per_frame * (my_queue + 1u) / kQueues) - q_first;
+                const uint32_t q_units = q_tiles * bp.n_frames * 64u;
                 unsigned int base = 0;
-                if (lane == 0) base = atomicAdd(work_counter, n_need);
+                if (lane == 0) base = atomicAdd(work_counter + my_queue * kQueueStride, n_need);
                 base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-                if (base + n_need >= total_units) exhausted = true;
                 uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-                if (L.mode == rt::kLaneNeedUnit) {
-                    uint32_t unit = base + rank;
-                    if (unit >= total_units) {
-                        L.mode = rt::kLaneDead;
-                    } else {
-                        uint32_t tile_all = unit >> 6, slot = unit & 63u;
-                        uint32_t frame_k = tile_all / tiles_per_frame, tile = tile_all % tiles_per_frame;
-                        int px = (int)((tile % tiles_x) * 8u + (slot & 7u));
-                        int ly = (int)((tile / tiles_x) * 8u + (slot >> 3));
-                        int py = stripe_global_row(sm, ly);
-                        if (px < fp.width && ly < local_rows && py < fp.height) {
-                            L.unit = unit;
-                            if (fp.max_bounces == 0u) {
-                                rt::lane_empty_pixel(L, park);
-                            } else {
-                                rt::FrameParams f = fp;
-                                if (!FUSED) f.seed_add = (uint32_t)(float)(bp.first_frame + frame_k * bp.stride) * 12345u;
-                                rt::lane_begin_pixel(sc, f, L, px, py, stack, park, n_rays, cp);
-                            }
+                uint32_t n = base + rank; // position in the queue
+                if (L.mode == rt::kLaneNeedUnit && n < q_units) {
+                    uint32_t frame_k = n / (q_tiles * 64u), rest = n % (q_tiles * 64u);
+                    uint32_t tile = q_first + (rest >> 6), slot = rest & 63u;
+                    int px = (int)((tile % tiles_x) * 8u + (slot & 7u));
+                    int ly = (int)((tile / tiles_x) * 8u + (slot >> 3));
+                    int py = stripe_global_row(sm, ly);
+                    if (px < fp.width && ly < local_rows && py < fp.height) {
+                        L.unit = (frame_k * tiles_per_frame + tile) * 64u + slot;
+                        if (fp.max_bounces == 0u) {
+                            rt::lane_empty_pixel(L, park);
+                        } else {
+                            rt::FrameParams f = fp;
+                            if (!FUSED) f.seed_add = (uint32_t)(float)(bp.first_frame + frame_k * bp.stride) * 12345u;
+                            rt::lane_begin_pixel(sc, f, L, px, py, stack, park, n_rays, cp);
                         }
                     }
+                }
+                // The queue ran out with this grab (lanes beyond its end got nothing and ask again): on to
+                // the next one; after leaving all of them behind there is no work left.
+                if (base + n_need >= q_units) {
+                    my_queue = (my_queue + 1u) % kQueues;
+                    if (++queues_left == kQueues) exhausted = true;
                 }
             }
         }
@@ -606,7 +629,7 @@ struct rt_context {
 
     // persistent-kernel launch state
     int n_cus = 0;
-    unsigned int *d_work = nullptr; // kWorkCounters tile counters, one per launch
+    unsigned int *d_work = nullptr; // ring of work-queue counters, kLaunchCounters per launch
     uint32_t work_used = 0;
     uint2 *d_batch = nullptr;       // frame colours of a batch
     size_t batch_capacity = 0;      // in frames
@@ -653,7 +676,8 @@ struct rt_context {
 
 namespace {
 
-constexpr uint32_t kWorkCounters = 4096;
+constexpr uint32_t kLaunchCounters = kQueues * kQueueStride; // counters one launch uses (128 dwords)
+constexpr uint32_t kWorkCounters = 64 * kLaunchCounters;     // ring of launches; far more than can be in flight
 constexpr size_t kBatchBytesCap = (size_t)2 << 30;
 constexpr uint64_t kUnitsPerLaunch = 64ull * 1920 * 1080;
 
@@ -802,7 +826,7 @@ int launch_persistent(rt_context *c, uint32_t first, uint32_t n, uint32_t stride
     while (done < n) {
         uint32_t b = std::min(max_batch, n - done);
         unsigned int *counter = c->d_work + c->work_used;
-        c->work_used = (c->work_used + 1) % kWorkCounters;
+        c->work_used = (c->work_used + kLaunchCounters) % kWorkCounters;
         if (c->no_alloc) counter = (unsigned int *)c->scratch; // launches on one stream run in order: one counter is enough
         c->uniforms[12] = (float)(first + done * stride);
         rt::FrameParams fp;
@@ -814,7 +838,7 @@ int launch_persistent(rt_context *c, uint32_t first, uint32_t n, uint32_t stride
         if (c->no_alloc) {
             // same kernels as the batch path below, colours in the fixed workspace
             bp.colors = (uint2 *)((unsigned char *)c->scratch + kScratchHeader);
-            RT_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned int), c->stream));
+            RT_HIP_CHECK(hipMemsetAsync(counter, 0, kLaunchCounters * sizeof(unsigned int), c->stream));
             rc = c->counting ? launch_persistent_d<true, false>(c, fp, bp, counter, c->stream)
                              : launch_persistent_d<false, false>(c, fp, bp, counter, c->stream);
             if (rc) return rc;
@@ -823,7 +847,7 @@ int launch_persistent(rt_context *c, uint32_t first, uint32_t n, uint32_t stride
             RT_HIP_CHECK(hipGetLastError());
         } else if (b == 1 && !c->tune_overlap) {
             // one frame, accumulated by the trace kernel itself
-            RT_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned int), c->stream));
+            RT_HIP_CHECK(hipMemsetAsync(counter, 0, kLaunchCounters * sizeof(unsigned int), c->stream));
             rc = c->counting ? launch_persistent_d<true, true>(c, fp, bp, counter, c->stream)
                              : launch_persistent_d<false, true>(c, fp, bp, counter, c->stream);
             if (rc) return rc;
@@ -841,7 +865,7 @@ int launch_persistent(rt_context *c, uint32_t first, uint32_t n, uint32_t stride
             bp.copy_ids = true;
             // rt_last_render_ms spans from the first trace to the last accumulate: restart its first event here
             if (done == 0) RT_HIP_CHECK(hipEventRecord(c->ev_start, c->aux[k]));
-            RT_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned int), c->aux[k]));
+            RT_HIP_CHECK(hipMemsetAsync(counter, 0, kLaunchCounters * sizeof(unsigned int), c->aux[k]));
             rc = c->counting ? launch_persistent_d<true, false>(c, fp, bp, counter, c->aux[k])
                              : launch_persistent_d<false, false>(c, fp, bp, counter, c->aux[k]);
             if (rc) return rc;
@@ -859,7 +883,7 @@ int launch_persistent(rt_context *c, uint32_t first, uint32_t n, uint32_t stride
                 c->batch_capacity = b;
             }
             bp.colors = c->d_batch;
-            RT_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned int), c->stream));
+            RT_HIP_CHECK(hipMemsetAsync(counter, 0, kLaunchCounters * sizeof(unsigned int), c->stream));
             rc = c->counting ? launch_persistent_d<true, false>(c, fp, bp, counter, c->stream)
                              : launch_persistent_d<false, false>(c, fp, bp, counter, c->stream);
             if (rc) return rc;
