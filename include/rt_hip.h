@@ -131,6 +131,18 @@ int rt_set_max_bounces(rt_context *ctx, uint32_t max_bounces);
  */
 int rt_set_sphere_lights(rt_context *ctx, int enable);
 
+/*
+ * Opt-in extension, off by default because it changes the image: the debug view.  The reference
+ * writes a debugEnabled uniform (src/webgpu-renderer.ts:228, setDebug :279-282) that no shader
+ * reads, and its shader library carries ray_triangle_normal_intersect (public/common.wgsl:235-240),
+ * which nothing calls: a marker sphere of radius 0.1, 0.2 along the normal from a triangle's
+ * centre, coloured by the normal.  With this switch on, frames whose uniforms have debugEnabled
+ * != 0 test every triangle's marker in ray_all right after the triangle, under the same selection
+ * rule; marker i reports the primary id n_spheres + n_triangles + i.  Such frames are rendered by
+ * the brute-force kernel whatever the mode (the markers are in no acceleration structure).
+ */
+int rt_set_debug_view(rt_context *ctx, int enable);
+
 /* Select the traversal (default RT_MODE_BVH).  All modes produce identical output. */
 int rt_set_mode(rt_context *ctx, int mode);
 
@@ -271,6 +283,15 @@ int rt_take_triangle_tests(rt_context *ctx, uint32_t *triangle_tests);
 int rt_owned_rows(rt_context *ctx, int *rows);
 int rt_export_owned_rows(rt_context *ctx, void *dst_device);
 int rt_import_rows(rt_context *ctx, const void *src_device, int from_index);
+/* The same exchange through host memory, for hosts that have no device buffers of their own (the
+ * Node addon): rt_read_owned_rows waits for the context and fills `planes` with 3*owned_rows*width
+ * float32 in the layout above; rt_write_rows scatters such a block that came from the context with
+ * stripe_index `from_index` into this context's accumulator planes and waits for it. */
+int rt_read_owned_rows(rt_context *ctx, float *planes);
+/* rt_rows_of_stripe: number of rows the context with stripe_index `stripe_index` (same image, same
+ * stripe_rows and stripe_count as this one) owns, i.e. the height of the block it exports. */
+int rt_rows_of_stripe(rt_context *ctx, int stripe_index, int *rows);
+int rt_write_rows(rt_context *ctx, const float *planes, int from_index);
 
 /*
  * Frame-split rendering across GPUs (no counterpart in the reference).  Frames

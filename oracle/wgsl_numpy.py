@@ -145,11 +145,22 @@ def ray_triangle_intersect(ro, rd, tr):  # common.wgsl:170-211; tr = 24 floats
     return Hit(t, tr[12:15], n, (tr[16:19] * tr[19]).astype(np.float32), tr[20], tr[21])
 
 
+def ray_triangle_normal_intersect(ro, rd, tr):  # common.wgsl:235-240 (never called by the shader)
+    center = (((tr[0:3] + tr[4:7]) + tr[8:11]) / f32(3.0)).astype(np.float32)
+    n = normalize(cross(tr[4:7] - tr[0:3], tr[8:11] - tr[0:3]))
+    s = np.zeros(16, dtype=np.float32)
+    s[0:3] = center + n * f32(0.2)
+    s[3] = f32(0.1)
+    s[4:7] = n
+    return ray_sphere_intersect(ro, rd, s)
+
+
 class Scene:
-    def __init__(self, spheres, tris):
+    def __init__(self, spheres, tris, debug_view=False):
         self.spheres = np.asarray(spheres, dtype=np.float32).reshape(-1, 16)
         self.tris = np.asarray(tris, dtype=np.float32).reshape(-1, 24)
         self.rays = 0
+        self.debug_view = debug_view   # extension: ray_all also tests every triangle's normal marker
 
 
 def ray_all(sc, ro, rd):  # raytracer_compute.wgsl:15-39
@@ -165,6 +176,11 @@ def ray_all(sc, ro, rd):  # raytracer_compute.wgsl:15-39
         if h.t > 0 and (closest.t < 0 or h.t < closest.t):
             closest = h
             closest.id = len(sc.spheres) + i
+        if sc.debug_view:   # extension: the marker follows its triangle, same rule; marker ids follow the triangles'
+            h = ray_triangle_normal_intersect(ro, rd, tr)
+            if h.t > 0 and (closest.t < 0 or h.t < closest.t):
+                closest = h
+                closest.id = len(sc.spheres) + len(sc.tris) + i
     return closest
 
 
@@ -348,7 +364,7 @@ def f16_round_trip(x):
         return np.asarray(x, dtype=np.float32).astype(np.float16)
 
 
-def render_frame(uniforms, spheres, tris, accum, max_bounces=6, sphere_lights=False):
+def render_frame(uniforms, spheres, tris, accum, max_bounces=6, sphere_lights=False, debug_view=False):
     """raytracer_compute.wgsl:280-341 + accumulator.wgsl:44-68 over the whole image.
     uniforms: 20 float32; accum: (3, H, W) float32 in/out.  Returns (frame_f16 (H,W,4) uint16,
     ids (H,W) int32, rays)."""
@@ -356,7 +372,7 @@ def render_frame(uniforms, spheres, tris, accum, max_bounces=6, sphere_lights=Fa
     cam_pos, cam_rot, fov_deg = u[0:3], u[4:7], u[7]
     frame_index, res_x, res_y, spp_f = u[12], u[14], u[15], u[16]
     W, H = int(res_x), int(res_y)
-    sc = Scene(spheres, tris)
+    sc = Scene(spheres, tris, debug_view=debug_view and u[17] != 0)
     frame = np.zeros((H, W, 4), dtype=np.uint16)
     ids = np.zeros((H, W), dtype=np.int32)
     aspect = f32(res_x / res_y)

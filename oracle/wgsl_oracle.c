@@ -79,6 +79,7 @@ typedef struct { /* common.wgsl:34-48, size 80 */
     float frameIndex;
     float res_x, res_y;
     float samplesPerPixel;
+    float debugEnabled;
 } UniV;
 
 static UniV load_uniforms(const void *p)
@@ -91,6 +92,7 @@ static UniV load_uniforms(const void *p)
     u.frameIndex = f[12];
     u.res_x = f[14]; u.res_y = f[15];
     u.samplesPerPixel = f[16];
+    u.debugEnabled = f[17];
     return u;
 }
 
@@ -293,7 +295,26 @@ typedef struct {
     const unsigned char *spheres; uint32_t n_spheres;
     const unsigned char *tris; uint32_t n_tris;
     int sphere_lights; /* ORC_SPHERE_LIGHTS: ray_trace also samples emissive spheres (an extension, see below) */
+    int debug_view;    /* ORC_DEBUG_VIEW: ray_all also tests every triangle's normal marker (an extension, see below) */
 } SceneV;
+
+/* common.wgsl:235-240: a sphere of radius 0.1 placed 0.2 along the normal from the triangle's centre,
+ * coloured by the normal.  The shader defines it and never calls it; ray_all below calls it only
+ * with ORC_DEBUG_VIEW. */
+static OrcHit ray_triangle_normal(v3 ro, v3 rd, const TriV *tri)
+{
+    v3 triangleCenter = vdivs(vadd(vadd(tri->v0, tri->v1), tri->v2), 3.0f);
+    v3 triangleNormal = vnormalize(vcross(vsub(tri->v1, tri->v0), vsub(tri->v2, tri->v0)));
+    SphereV sp;
+    sp.center = vadd(triangleCenter, vscale(triangleNormal, 0.2f));
+    sp.radius = 0.1f;
+    sp.color = triangleNormal;
+    sp.smoothness = 0.0f;
+    sp.emissionColor = V(0.0f, 0.0f, 0.0f);
+    sp.emissionStrength = 0.0f;
+    sp.specularProbability = 0.0f;
+    return ray_sphere(ro, rd, &sp);
+}
 
 static OrcHit ray_all(v3 ro, v3 rd, const SceneV *sc) /* raytracer_compute.wgsl:15-39 */
 {
@@ -312,6 +333,17 @@ static OrcHit ray_all(v3 ro, v3 rd, const SceneV *sc) /* raytracer_compute.wgsl:
         if (hit.t > 0.0f && (closest.t < 0.0f || hit.t < closest.t)) {
             closest = hit;
             closest.id = (int32_t)(sc->n_spheres + i);
+        }
+        /* Extension, off unless ORC_DEBUG_VIEW: the debug view that uniforms.debugEnabled
+         * (src/webgpu-renderer.ts:228) and ray_triangle_normal_intersect were written for and that the
+         * shader never got: the marker of each triangle is one more candidate, right after its
+         * triangle, under the same selection rule; ids of markers follow those of the triangles. */
+        if (sc->debug_view) {
+            OrcHit mark = ray_triangle_normal(ro, rd, &tr);
+            if (mark.t > 0.0f && (closest.t < 0.0f || mark.t < closest.t)) {
+                closest = mark;
+                closest.id = (int32_t)(sc->n_spheres + sc->n_tris + i);
+            }
         }
     }
     return closest;
@@ -744,6 +776,8 @@ int orc_render_frame_ex(const void *uniforms80,
     j.sc.spheres = (const unsigned char *)spheres; j.sc.n_spheres = n_spheres;
     j.sc.tris = (const unsigned char *)tris; j.sc.n_tris = n_tris;
     j.sc.sphere_lights = (flags & ORC_SPHERE_LIGHTS) != 0u;
+    /* the debug view is drawn only while the uniform says so, as a shader reading it would */
+    j.sc.debug_view = (flags & ORC_DEBUG_VIEW) != 0u && j.u.debugEnabled != 0.0f;
     j.max_bounces = max_bounces;
     j.x0 = x0; j.y0 = y0; j.x1 = x1; j.y1 = y1;
     j.accum = accum; j.frame_f16 = frame_f16; j.ids = ids;
@@ -782,7 +816,7 @@ void orc_ray_all(const float origin[3], const float dir[3],
                  const void *spheres, uint32_t n_spheres,
                  const void *tris, uint32_t n_tris, OrcHit *out)
 {
-    SceneV sc = {(const unsigned char *)spheres, n_spheres, (const unsigned char *)tris, n_tris, 0};
+    SceneV sc = {(const unsigned char *)spheres, n_spheres, (const unsigned char *)tris, n_tris, 0, 0};
     *out = ray_all(ld3(origin), ld3(dir), &sc);
 }
 
@@ -791,7 +825,7 @@ float orc_sample_light_triangles(const float hit_point[3], uint32_t *state,
                                  float out_dir[3], float out_emission[3],
                                  float *out_distance)
 {
-    SceneV sc = {NULL, 0, (const unsigned char *)tris, n_tris, 0};
+    SceneV sc = {NULL, 0, (const unsigned char *)tris, n_tris, 0, 0};
     LightSample s = sample_light_triangles(ld3(hit_point), state, &sc);
     st3(out_dir, s.direction);
     st3(out_emission, s.emission);
@@ -819,7 +853,7 @@ void orc_ray_trace(const float origin[3], const float dir[3], uint32_t max_bounc
                    const void *tris, uint32_t n_tris, float out_light[3],
                    uint64_t *n_rays, int32_t *first_id)
 {
-    SceneV sc = {(const unsigned char *)spheres, n_spheres, (const unsigned char *)tris, n_tris, 0};
+    SceneV sc = {(const unsigned char *)spheres, n_spheres, (const unsigned char *)tris, n_tris, 0, 0};
     uint64_t local = 0;
     int32_t fid = -1;
     st3(out_light, ray_trace(ld3(origin), ld3(dir), max_bounces, state, &sc, &local, &fid));

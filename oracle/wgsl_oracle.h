@@ -121,8 +121,16 @@ int orc_render_frame(const void *uniforms80,
  * never called) through a second shadow ray, wired like the triangle-light block at
  * :211-225.  The reference does not do this (its TODO at :226); it is an extension that
  * renderer and oracle share, off by default.
+ *
+ * ORC_DEBUG_VIEW: while uniforms.debugEnabled is non-zero, ray_all also tests, right after each
+ * triangle, the marker sphere of ray_triangle_normal_intersect (common.wgsl:235-240, defined there
+ * and never called): radius 0.1, 0.2 along the normal from the triangle's centre, coloured by the
+ * normal.  Marker i reports id n_spheres + n_tris + i.  Also an extension shared by renderer and
+ * oracle, off by default: the reference writes debugEnabled (src/webgpu-renderer.ts:228) and no
+ * shader reads it.
  */
 #define ORC_SPHERE_LIGHTS 1u
+#define ORC_DEBUG_VIEW 2u
 int orc_render_frame_ex(const void *uniforms80,
                         const void *spheres, uint32_t n_spheres,
                         const void *tris, uint32_t n_tris,

@@ -34,6 +34,7 @@ SYMBOLS = {
     "rt_set_max_bounces": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rt_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_set_sphere_lights": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_set_debug_view": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_set_counting": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rt_render_frame": (C.c_int, [C.c_void_p]),
@@ -50,6 +51,9 @@ SYMBOLS = {
     "rt_owned_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "rt_export_owned_rows": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_import_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "rt_read_owned_rows": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_rows_of_stripe": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "rt_write_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "rt_clear_accum": (C.c_int, [C.c_void_p]),
     "rt_render_frame_sums": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rt_export_accum": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -212,6 +216,20 @@ class Context:
     def import_rows(self, device_ptr: int, from_index: int):
         _check(self.lib.rt_import_rows(self.handle, C.c_void_p(device_ptr), from_index))
 
+    def rows_of_stripe(self, stripe_index: int) -> int:
+        v = C.c_int()
+        _check(self.lib.rt_rows_of_stripe(self.handle, stripe_index, C.byref(v)))
+        return v.value
+
+    def read_owned_rows(self) -> np.ndarray:
+        out = np.empty((3, self.owned_rows(), self.width), dtype=np.float32)
+        _check(self.lib.rt_read_owned_rows(self.handle, _ptr(out)))
+        return out
+
+    def write_rows(self, planes: np.ndarray, from_index: int):
+        planes = np.ascontiguousarray(planes, dtype=np.float32)
+        _check(self.lib.rt_write_rows(self.handle, _ptr(planes), from_index))
+
     def clear_accum(self):
         _check(self.lib.rt_clear_accum(self.handle))
 
@@ -231,6 +249,9 @@ class Context:
         v = C.c_uint32()
         _check(self.lib.rt_frames_per_launch(self.handle, C.byref(v)))
         return v.value
+
+    def set_debug_view(self, enable: bool):
+        _check(self.lib.rt_set_debug_view(self.handle, 1 if enable else 0))
 
     def set_sphere_lights(self, enable: bool):
         _check(self.lib.rt_set_sphere_lights(self.handle, 1 if enable else 0))

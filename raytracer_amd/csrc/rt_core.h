@@ -139,6 +139,7 @@ struct SceneView {
     float total_power;
     int32_t root;            // root link (leaf-encoded when the tree is one leaf); 0x7fffffff if no triangles
     int32_t root4;           // the same for the 4-wide tree
+    uint32_t debug_view;     // opt-in extension (brute-force ray_all only): every triangle's normal marker is tested too
 };
 
 constexpr int32_t kNoRoot = 0x7fffffff;
@@ -376,6 +377,17 @@ RT_HD bool trace_occluded(const SceneView &sc, f3 ro, f3 rd, float limit, Stack 
     return false;
 }
 
+// The marker of a triangle in the debug view (common.wgsl:235-240, ray_triangle_normal_intersect,
+// which the shader defines and never calls): a sphere of radius 0.1 placed 0.2 along the normal
+// from the triangle's centre.  r: the triangle's 96-byte record.  Returns (centre, radius).
+RT_HD f4 marker_sphere(const f4 *r)
+{
+    f3 v0 = xyz(r[0]), v1 = xyz(r[1]), v2 = xyz(r[2]);
+    f3 center = divs(add(add(v0, v1), v2), 3.0f);
+    f3 normal = normalize(cross(sub(v1, v0), sub(v2, v0)));
+    return mk4(add(center, scale(normal, 0.2f)), 0.1f);
+}
+
 // Brute-force ray_all exactly as raytracer_compute.wgsl:15-39 over the raw
 // 96-byte triangle records (edges and normal recomputed per test).
 RT_HD int32_t brute_closest(const SceneView &sc, f3 ro, f3 rd, float &out_t)
@@ -392,10 +404,18 @@ RT_HD int32_t brute_closest(const SceneView &sc, f3 ro, f3 rd, float &out_t)
         f3 v0 = xyz(r[0]), v1 = xyz(r[1]), v2 = xyz(r[2]);
         f3 e01 = sub(v1, v0), e02 = sub(v2, v0);
         float t = triangle_t(ro, rd, v0, e01, e02);
-        if (t < 0.0f) continue; // the miss record of common.wgsl:180-199
-        f3 nrm = normalize(cross(e01, e02));
-        if (dot(nrm, rd) > 0.0f) continue;
-        if (t > 0.0f && (closest_t < 0.0f || t < closest_t)) { closest_t = t; closest_id = (int32_t)(sc.n_spheres + i); }
+        if (!(t < 0.0f)) { // otherwise the miss record of common.wgsl:180-199
+            f3 nrm = normalize(cross(e01, e02));
+            if (!(dot(nrm, rd) > 0.0f) && t > 0.0f && (closest_t < 0.0f || t < closest_t)) {
+                closest_t = t;
+                closest_id = (int32_t)(sc.n_spheres + i);
+            }
+        }
+        if (sc.debug_view) { // the triangle's marker is the next candidate, same rule; marker ids follow the triangles'
+            float tn;
+            float tm = sphere_t(ro, rd, marker_sphere(r), tn);
+            if (tm > 0.0f && (closest_t < 0.0f || tm < closest_t)) { closest_t = tm; closest_id = (int32_t)(sc.n_spheres + sc.n_tris + i); }
+        }
     }
     out_t = closest_t;
     return closest_id;
@@ -420,6 +440,18 @@ RT_HD Hit fetch_hit(const SceneView &sc, f3 ro, f3 rd, int32_t id, float t)
         h.smoothness = s1.w;
         h.emission = scale(xyz(s2), s2.w);
         h.specularProbability = s3.x;
+    } else if ((uint32_t)id >= sc.n_spheres + sc.n_tris) {
+        // a marker of the debug view: the Sphere(centre, 0.1, normal, 0, vec3(), 0, 0) of common.wgsl:239
+        const f4 *r = sc.tri_raw + 6 * (size_t)((uint32_t)id - sc.n_spheres - sc.n_tris);
+        f4 s0 = marker_sphere(r);
+        float tn = t;
+        if (!(t > 0.01f)) (void)sphere_t(ro, rd, s0, tn);
+        f3 hit_point = add(ro, scale(rd, tn));
+        h.normal = normalize(sub(hit_point, xyz(s0)));
+        h.color = normalize(cross(sub(xyz(r[1]), xyz(r[0])), sub(xyz(r[2]), xyz(r[0]))));
+        h.smoothness = 0.0f;
+        h.emission = scale(mk3(0.0f, 0.0f, 0.0f), 0.0f);
+        h.specularProbability = 0.0f;
     } else {
         const f4 *s = sc.tri_shade + 3 * (size_t)((uint32_t)id - sc.n_spheres);
         f4 a = s[0], b = s[1], c = s[2];

@@ -663,6 +663,7 @@ struct rt_context {
     }
     int tune_max_stack = 64;
     int tune_shade_wait = 12;
+    bool debug_view = false;    // opt-in extension: uniforms.debugEnabled draws the triangles' normal markers (brute-force kernel)
     bool sphere_lights = false; // opt-in extension: emissive spheres are sampled too (one-thread-per-pixel kernel)
     int tune_shade_num = 2, tune_leaf_lanes = 12, tune_blocks_per_cu = 0, tune_batch = 0, tune_sdone_lanes = 2, tune_refill_lanes = 0, tune_max_leaf = 4, tune_tri_cost_x10 = 12, tune_lds_state = RT_LDS_PARK;
 
@@ -681,16 +682,21 @@ constexpr uint32_t kWorkCounters = 64 * kLaunchCounters;     // ring of launches
 constexpr size_t kBatchBytesCap = (size_t)2 << 30;
 constexpr uint64_t kUnitsPerLaunch = 64ull * 1920 * 1080;
 
+// The debug view is drawn while the extension is switched on and the uniforms ask for it.
+bool debug_view_active(const rt_context *c) { return c->debug_view && c->uniforms[17] != 0.0f; }
+
 int launch_tiles(rt_context *c, const rt::FrameParams &fp, bool sum)
 {
     dim3 block(kBlock);
     dim3 grid((c->width + 31) / 32, (c->local_rows + 7) / 8);
     if (grid.x == 0 || grid.y == 0) return RT_OK;
     uint32_t depth = c->host_scene.max_depth;
+    rt::SceneView view = c->view;
+    view.debug_view = debug_view_active(c) ? 1u : 0u;
 #define RT_LAUNCH_A(BRUTE, STACK, COUNT)                                                                        \
-    hipLaunchKernelGGL((render_tiles_kernel<BRUTE, STACK, COUNT>), grid, block, 0, c->stream, c->view, fp, c->sm, \
+    hipLaunchKernelGGL((render_tiles_kernel<BRUTE, STACK, COUNT>), grid, block, 0, c->stream, view, fp, c->sm, \
                        c->local_rows, c->fb, sum)
-    if (c->mode == RT_MODE_BRUTE_FORCE) {
+    if (c->mode == RT_MODE_BRUTE_FORCE || view.debug_view) { // the markers are in no tree: every primitive per ray
         RT_LAUNCH_A(true, 1, false);
     } else if (c->counting) {
         if (depth < 16) RT_LAUNCH_A(false, 16, true);
@@ -1067,6 +1073,7 @@ static int upload_scene(rt_context *c, const void *spheres, uint32_t n_spheres, 
     v.spheres = c->d_spheres; v.lights = c->d_lights;
     v.n_spheres = hs.n_spheres; v.n_tris = hs.n_tris; v.n_lights = hs.n_lights; v.n_lights_pass1 = hs.n_lights_pass1;
     v.total_power = hs.total_power; v.root = hs.root;
+    v.debug_view = 0u;
     c->has_scene = true;
     return RT_OK;
 }
@@ -1141,6 +1148,14 @@ int rt_set_sphere_lights(rt_context *c, int enable)
     return RT_OK;
 }
 
+int rt_set_debug_view(rt_context *c, int enable)
+{
+    if (!c) return fail(RT_ERR_INVALID, "null context");
+    RT_FLUSH_PENDING(c);
+    c->debug_view = enable != 0;
+    return RT_OK;
+}
+
 int rt_set_mode(rt_context *c, int mode)
 {
     if (!c) return fail(RT_ERR_INVALID, "null context");
@@ -1189,7 +1204,7 @@ static int render_frames_impl(rt_context *c, uint32_t first_frame_index, uint32_
     RT_HIP_CHECK(hipSetDevice(c->device));
     if ((rc = ensure_padding_covers_camera(c))) return rc;
     RT_HIP_CHECK(hipEventRecord(c->ev_start, c->stream));
-    if (c->mode == RT_MODE_BVH && !c->sphere_lights && persistent_stack_need(c) <= (uint32_t)c->tune_max_stack) {
+    if (c->mode == RT_MODE_BVH && !c->sphere_lights && !debug_view_active(c) && persistent_stack_need(c) <= (uint32_t)c->tune_max_stack) {
         if ((rc = launch_persistent(c, first_frame_index, n_frames, stride, sum))) return rc;
     } else {
         for (uint32_t k = 0; k < n_frames; k++) {
@@ -1276,7 +1291,7 @@ int rt_render_frame(rt_context *c)
     int rc = check_ready(c);
     if (rc) return rc;
     uint32_t frame = (uint32_t)c->uniforms[12];
-    bool coalesce = c->tune_coalesce > 1 && c->mode == RT_MODE_BVH && !c->sphere_lights && !c->counting &&
+    bool coalesce = c->tune_coalesce > 1 && c->mode == RT_MODE_BVH && !c->sphere_lights && !debug_view_active(c) && !c->counting &&
                     persistent_stack_need(c) <= (uint32_t)c->tune_max_stack;
     if (!coalesce) {
         RT_FLUSH_PENDING(c);
@@ -1441,6 +1456,56 @@ int rt_import_rows(rt_context *c, const void *src_device, int from_index)
                        (const float *)src_device, c->width, c->height, rows, sm);
     RT_HIP_CHECK(hipGetLastError());
     return RT_OK;
+}
+
+int rt_rows_of_stripe(rt_context *c, int stripe_index, int *rows)
+{
+    if (!c || !rows) return fail(RT_ERR_INVALID, "null argument");
+    if (stripe_index < 0 || stripe_index >= c->sm.count) return fail(RT_ERR_INVALID, "stripe_index out of range");
+    StripeMap sm = c->sm;
+    sm.index = stripe_index;
+    *rows = owned_rows_of(c->height, sm);
+    return RT_OK;
+}
+
+int rt_read_owned_rows(rt_context *c, float *planes)
+{
+    if (!c || !planes) return fail(RT_ERR_INVALID, "null argument");
+    RT_FLUSH_PENDING(c);
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    size_t n = (size_t)c->local_rows * c->width;
+    if (n == 0) return RT_OK;
+    float *tmp = nullptr;
+    RT_HIP_CHECK(hipMalloc((void **)&tmp, n * 3 * sizeof(float)));
+    hipLaunchKernelGGL(export_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->fb.accum, tmp, c->width,
+                       c->height, c->local_rows, c->sm);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(planes, tmp, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("rt_read_owned_rows: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_write_rows(rt_context *c, const float *planes, int from_index)
+{
+    if (!c || !planes) return fail(RT_ERR_INVALID, "null argument");
+    if (from_index < 0 || from_index >= c->sm.count) return fail(RT_ERR_INVALID, "from_index out of range");
+    RT_FLUSH_PENDING(c);
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    StripeMap sm = c->sm;
+    sm.index = from_index;
+    size_t n = (size_t)owned_rows_of(c->height, sm) * c->width;
+    if (n == 0) return RT_OK;
+    float *tmp = nullptr;
+    RT_HIP_CHECK(hipMalloc((void **)&tmp, n * 3 * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(tmp, planes, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    int rc = RT_OK;
+    if (e == hipSuccess) rc = rt_import_rows(c, tmp, from_index);
+    if (e == hipSuccess && rc == RT_OK) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("rt_write_rows: ") + hipGetErrorString(e));
+    return rc;
 }
 
 int rt_frames_per_launch(rt_context *c, uint32_t *frames)

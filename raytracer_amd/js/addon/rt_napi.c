@@ -206,6 +206,7 @@ INT_SETTER(js_set_max_bounces, rt_set_max_bounces(ctx, (uint32_t)v))
 INT_SETTER(js_set_mode, rt_set_mode(ctx, v))
 INT_SETTER(js_set_counting, rt_set_counting(ctx, v))
 INT_SETTER(js_set_sphere_lights, rt_set_sphere_lights(ctx, v))
+INT_SETTER(js_set_debug_view, rt_set_debug_view(ctx, v))
 
 static napi_value js_set_tuning(napi_env env, napi_callback_info info)
 {
@@ -343,13 +344,52 @@ static napi_value js_owned_rows(napi_env env, napi_callback_info info)
     return out;
 }
 
+/* Accumulator rows the context owns, as three planes (R, G, B) of ownedRows x width floats. */
+static napi_value js_read_owned_rows(napi_env env, napi_callback_info info)
+{
+    napi_value a[1], ab, out;
+    if (!get_args(env, info, 1, a)) return NULL;
+    NEED_CTX(ctx, a[0]);
+    handle_box *box = get_box(env, a[0]);
+    int rows = 0;
+    if (rt_owned_rows(ctx, &rows) != RT_OK) return throw_rt(env, "rt_owned_rows");
+    size_t n = (size_t)rows * box->width * 3;
+    void *data = NULL;
+    NAPI_OK(napi_create_arraybuffer(env, n * sizeof(float), &data, &ab));
+    if (n && rt_read_owned_rows(ctx, (float *)data) != RT_OK) return throw_rt(env, "rt_read_owned_rows");
+    NAPI_OK(napi_create_typedarray(env, napi_float32_array, n, ab, 0, &out));
+    return out;
+}
+
+/* (handle, Float32Array block of the context with stripe index fromIndex, fromIndex) */
+static napi_value js_write_rows(napi_env env, napi_callback_info info)
+{
+    napi_value a[3];
+    if (!get_args(env, info, 3, a)) return NULL;
+    NEED_CTX(ctx, a[0]);
+    handle_box *box = get_box(env, a[0]);
+    float *data;
+    size_t n;
+    int32_t from;
+    if (!get_f32_array(env, a[1], &data, &n) || !get_i32(env, a[2], &from)) return NULL;
+    int rows = 0;
+    if (rt_rows_of_stripe(ctx, from, &rows) != RT_OK) return throw_rt(env, "rt_rows_of_stripe");
+    if (n != (size_t)rows * box->width * 3) {
+        napi_throw_range_error(env, NULL, "block size differs from 3 * rows of that stripe * width");
+        return NULL;
+    }
+    if (n && rt_write_rows(ctx, data, from) != RT_OK) return throw_rt(env, "rt_write_rows");
+    return NULL;
+}
+
 static napi_value init(napi_env env, napi_value exports)
 {
     static const struct { const char *name; napi_callback fn; } fns[] = {
         {"deviceCount", js_device_count}, {"create", js_create}, {"destroy", js_destroy},
         {"setScene", js_set_scene}, {"setUniforms", js_set_uniforms}, {"setMaxBounces", js_set_max_bounces},
         {"setMode", js_set_mode}, {"setCounting", js_set_counting}, {"setTuning", js_set_tuning},
-        {"setSphereLights", js_set_sphere_lights},
+        {"setSphereLights", js_set_sphere_lights}, {"setDebugView", js_set_debug_view},
+        {"readOwnedRows", js_read_owned_rows}, {"writeRows", js_write_rows},
         {"renderFrame", js_render_frame}, {"renderFrames", js_render_frames}, {"sync", js_sync},
         {"lastRenderMs", js_last_render_ms}, {"readAccum", js_read_accum}, {"readFrameF16", js_read_frame_f16},
         {"readPrimaryIds", js_read_primary_ids}, {"readCounters", js_read_counters},

@@ -22,6 +22,8 @@ export interface HipRendererOptions {
     applyModelTransforms?: boolean;
     /** Sample emissive spheres as well as emissive triangles at every bounce. Off by default. */
     sphereLights?: boolean;
+    /** Make setDebug(true) draw every triangle's normal marker (common.wgsl:235-240). Off by default. */
+    debugView?: boolean;
 }
 
 export class HipRenderer {
@@ -48,5 +50,9 @@ export class HipRenderer {
     readFrameF16(): Uint16Array;
     getCounters(): number[];
     lastRenderMs(): number;
+    // multi-GPU row split: rows this renderer owns, their accumulator values (R, G, B planes), and assembly
+    ownedRows(): number;
+    readOwnedRows(): Float32Array;
+    importRows(block: Float32Array, fromIndex: number): void;
     destroy(): void;
 }

@@ -41,8 +41,10 @@ class HipRenderer {
     }
 
     // src/webgpu-renderer.ts:48-103.  options: { device, maxBounces, stripeRows, stripeIndex, stripeCount,
-    // presentEvery, applyModelTransforms, sphereLights }: sphereLights samples emissive spheres too (the shader's
-    // unused sample_light_spheres; off by default, changes the image); applyModelTransforms applies a model's scale / rotation / position, which the
+    // presentEvery, applyModelTransforms, sphereLights, debugView }: sphereLights samples emissive spheres too (the shader's
+    // unused sample_light_spheres; off by default, changes the image); debugView makes setDebug(true) draw every
+    // triangle's normal marker (the shader's unused ray_triangle_normal_intersect; off by default: the reference's
+    // setDebug changes nothing on screen); applyModelTransforms applies a model's scale / rotation / position, which the
     // reference reads and ignores (off by default); presentEvery = k copies the image into canvas.pixels on every k-th frame only (default 1,
     // every frame as the reference's canvas pass does; the copy reads the accumulator back and so waits for the GPU)
     static async Create(canvas, scenePath, options) {
@@ -58,6 +60,8 @@ class HipRenderer {
                 if (opt.maxBounces !== undefined) renderer.native.setMaxBounces(renderer.handle, opt.maxBounces);
                 renderer.presentEvery = Math.max(1, opt.presentEvery | 0);
                 if (opt.sphereLights) renderer.native.setSphereLights(renderer.handle, 1);
+                if (opt.debugView) renderer.native.setDebugView(renderer.handle, 1);
+                renderer.stripe = { rows: opt.stripeRows || 8, index: opt.stripeIndex || 0, count: opt.stripeCount || 1 };
             } catch (error) {
                 throw new RethrownError('Failed to create pipelines', error);
             }
@@ -184,6 +188,23 @@ class HipRenderer {
 
     readFrameF16() {
         return this.native.readFrameF16(this.handle, this.resolution.width, this.resolution.height);
+    }
+
+    // Multi-GPU row split (no counterpart in the reference): a renderer created with
+    // { stripeIndex: i, stripeCount: n } renders the rows y with floor(y / stripeRows) % n == i.
+    // ownedRows(): how many; readOwnedRows(): their accumulator values as three planes (R, G, B) of
+    // ownedRows x width floats, in increasing y; importRows(block, i): on the renderer that assembles
+    // the image, scatter the block read from the renderer with stripe index i into the accumulator.
+    ownedRows() {
+        return this.native.ownedRows(this.handle);
+    }
+
+    readOwnedRows() {
+        return this.native.readOwnedRows(this.handle);
+    }
+
+    importRows(block, fromIndex) {
+        this.native.writeRows(this.handle, block, fromIndex);
     }
 
     getCounters() {

@@ -40,7 +40,7 @@ extern "C" int har_render_frame(const void *uniforms80, const void *spheres, uin
     std::string err;
     if (!rt::make_frame_params(uniforms80, max_bounces, fp, err)) return -1;
     fp.sphere_lights = g_sphere_lights ? 1u : 0u;
-    rt::SceneView sc;
+    rt::SceneView sc{};
     sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data();
     sc.tri_raw = bs.tri_raw.data(); sc.spheres = bs.spheres.data(); sc.lights = bs.lights.data();
     sc.n_spheres = bs.n_spheres; sc.n_tris = bs.n_tris; sc.n_lights = bs.n_lights;
@@ -100,7 +100,7 @@ extern "C" int har_debug_pixel(const void *uniforms80, const void *spheres, uint
     rt::FrameParams fp;
     std::string err;
     if (!rt::make_frame_params(uniforms80, max_bounces, fp, err)) return -1;
-    rt::SceneView sc;
+    rt::SceneView sc{};
     sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data();
     sc.tri_raw = bs.tri_raw.data(); sc.spheres = bs.spheres.data(); sc.lights = bs.lights.data();
     sc.n_spheres = bs.n_spheres; sc.n_tris = bs.n_tris; sc.n_lights = bs.n_lights;
@@ -172,7 +172,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
     rt::FrameParams fp;
     std::string err;
     if (!rt::make_frame_params(uni, max_bounces, fp, err)) return -1;
-    rt::SceneView sc;
+    rt::SceneView sc{};
     sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data();
     sc.tri_raw = bs.tri_raw.data(); sc.spheres = bs.spheres.data(); sc.lights = bs.lights.data();
     sc.n_spheres = bs.n_spheres; sc.n_tris = bs.n_tris; sc.n_lights = bs.n_lights;

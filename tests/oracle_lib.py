@@ -169,7 +169,7 @@ class OracleRenderer:
     frame; the accumulator planes persist; reset only zeroes frameIndex."""
 
     def __init__(self, scene, width: int, height: int, max_bounces: int = 6, threads: int = 0,
-                 rect=None, sphere_lights: bool = False):
+                 rect=None, sphere_lights: bool = False, debug_view: bool = False):
         from raytracer_amd import scene as S
 
         self._S = S
@@ -177,6 +177,8 @@ class OracleRenderer:
         self.width, self.height = width, height
         self.max_bounces = max_bounces
         self.sphere_lights = sphere_lights   # ORC_SPHERE_LIGHTS extension
+        self.debug_view = debug_view         # ORC_DEBUG_VIEW extension: honour debug_enabled
+        self.debug_enabled = False           # the uniform the reference's setDebug writes
         self.threads = threads or (os.cpu_count() or 1)
         if isinstance(scene, tuple):  # (camera, packed spheres, packed triangles)
             self.scene = S.Scene(camera=scene[0])
@@ -201,11 +203,12 @@ class OracleRenderer:
     def render(self):
         self.frame_index += 1
         u = self._S.pack_uniforms(self.scene.camera, self.frame_index, self.width, self.height,
-                                  self.samples_per_pixel)
+                                  self.samples_per_pixel, self.debug_enabled)
         x0, y0, x1, y1 = self.rect
         rc = lib().orc_render_frame_ex(_ptr(u), _ptr(self.spheres), len(self.spheres), _ptr(self.tris), len(self.tris),
                                        self.max_bounces, x0, y0, x1, y1, _ptr(self.accum), _ptr(self.frame_f16),
-                                       _ptr(self.ids), _ptr(self.counters), self.threads, 1 if self.sphere_lights else 0)
+                                       _ptr(self.ids), _ptr(self.counters), self.threads,
+                                       (1 if self.sphere_lights else 0) | (2 if self.debug_view else 0))
         if rc != 0:
             raise RuntimeError("orc_render_frame failed: %d" % rc)
 

@@ -501,3 +501,62 @@ def test_single_frame_submissions_are_coalesced_without_changing_results(scenes,
     assert np.array_equal(ctx.read_accum(), orc.accum_rgb())
     assert np.array_equal(ctx.read_primary_ids(), orc.ids)
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", [capi.RT_MODE_BVH, capi.RT_MODE_BRUTE_FORCE, capi.RT_MODE_BVH_TILES])
+def test_debug_view_extension(scenes, mode):
+    """rt_set_debug_view: while uniforms.debugEnabled is set, every triangle's normal marker
+    (the shader's unused ray_triangle_normal_intersect) is one more candidate in ray_all; bit-exact
+    against the oracle built with the same option, in every mode (such frames go to the brute-force
+    kernel), single frames and a batch, switched off again in between."""
+    scene = scenes["boxes"]
+    width, height, spp = 96, 54, 2
+    orc = O.OracleRenderer(scene, width, height, debug_view=True)
+    orc.set_samples_per_pixel(spp)
+    ctx = capi.Context(width, height)
+    ctx.set_mode(mode)
+    ctx.set_debug_view(True)
+    ctx.set_scene(S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles))
+    for f, dbg in ((1, True), (2, True), (3, False), (4, True)):
+        orc.debug_enabled = dbg
+        orc.render()
+        ctx.set_uniforms(S.pack_uniforms(scene.camera, f, width, height, spp, dbg))
+        ctx.render_frame()
+    assert np.array_equal(ctx.read_primary_ids(), orc.ids)
+    assert (orc.ids >= 1 + 34).any()
+    orc.render_frames(2)
+    ctx.render_frames(5, 2)
+    assert np.array_equal(ctx.read_primary_ids(), orc.ids)
+    assert _f16_equal(ctx.read_frame_f16(), orc.frame_f16)
+    assert np.array_equal(ctx.read_accum(), orc.accum_rgb())
+    assert int(ctx.read_counters()[0]) == int(orc.counters[0])
+    ctx.close()
+
+
+def test_host_staged_row_exchange(scenes):
+    """rt_read_owned_rows / rt_write_rows / rt_rows_of_stripe: the row exchange through host memory
+    that the Node addon uses, against the device-pointer path's result (the unstriped oracle image)."""
+    scene = scenes["spheres"]
+    width, height, spp, count = 72, 45, 2, 3
+    orc = O.OracleRenderer(scene, width, height)
+    orc.set_samples_per_pixel(spp)
+    orc.render_frames(2)
+    ctxs = []
+    for i in range(count):
+        ctx = capi.Context(width, height, stripe_rows=8, stripe_index=i, stripe_count=count)
+        ctx.set_scene(S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles))
+        ctx.set_uniforms(S.pack_uniforms(scene.camera, 1, width, height, spp))
+        ctx.render_frame()
+        ctx.set_uniforms(S.pack_uniforms(scene.camera, 2, width, height, spp))
+        ctx.render_frame()      # may still be held back: the read below must launch it first
+        ctxs.append(ctx)
+    from raytracer_amd import sharding
+    for i in range(1, count):
+        block = ctxs[i].read_owned_rows()
+        assert block.shape[1] == ctxs[0].rows_of_stripe(i) == len(sharding.owned_rows(height, 8, i, count))
+        ctxs[0].write_rows(block, i)
+    assert np.array_equal(ctxs[0].read_accum(), orc.accum_rgb())
+    with pytest.raises(capi.RtError):
+        ctxs[0].rows_of_stripe(count)
+    for ctx in ctxs:
+        ctx.close()

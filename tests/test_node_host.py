@@ -180,3 +180,60 @@ HipRenderer.Create(canvas, '%(scene)s', { presentEvery: 4 }).then((r) => {
     orc.render_frames(info["frames"])
     acc = np.fromfile(tmp_path / "loop.f32", np.float32).reshape(height, width, 3)
     assert np.array_equal(acc, orc.accum_rgb())
+
+
+@pytest.mark.gpu
+def test_js_row_split_assembles_the_unstriped_image(scenes, tmp_path):
+    """raytracer_amd/js/multi-gpu.js with three striped renderers on the one GPU of the box: rows read
+    back with readOwnedRows, assembled with importRows on the first renderer; bit-equal to the oracle."""
+    width, height, spp, frames = 100, 61, 2, 3
+    script = """
+const fs = require('fs');
+const { renderSplit } = require('%(js)s/multi-gpu');
+renderSplit('%(scene)s', { width: %(w)d, height: %(h)d, spp: %(spp)d, frames: %(f)d, devices: [0, 0, 0] }).then((r) => {
+  fs.writeFileSync('%(out)s', Buffer.from(r.accum.buffer));
+  console.log(JSON.stringify({ rays: r.rays }));
+}).catch((e) => { console.error(e); process.exit(1); });
+""" % dict(js=JS, w=width, h=height, spp=spp, f=frames, scene=S.scene_path("suzanne"), out=str(tmp_path / "split.f32"))
+    info = json.loads(node(script).strip().splitlines()[-1])
+    orc = O.OracleRenderer(scenes["suzanne"], width, height)
+    orc.set_samples_per_pixel(spp)
+    orc.render_frames(frames)
+    acc = np.fromfile(tmp_path / "split.f32", np.float32).reshape(height, width, 3)
+    assert np.array_equal(acc, orc.accum_rgb())
+    assert info["rays"] == int(orc.counters[0])
+
+
+@pytest.mark.gpu
+def test_js_debug_view(scenes, tmp_path):
+    """Create(..., { debugView: true }) + setDebug(true): the triangles' normal markers are drawn (the
+    extension of rt_set_debug_view), bit-equal to the oracle with the same option; setDebug(true) without
+    the option changes nothing, as in the reference."""
+    width, height, spp = 64, 36, 2
+    script = """
+const fs = require('fs');
+const { HipRenderer } = require('%(js)s/hip-renderer');
+(async () => {
+  for (const debugView of [true, false]) {
+    const r = await HipRenderer.Create({ width: %(w)d, height: %(h)d }, '%(scene)s', { debugView });
+    r.setSamplesPerPixel(%(spp)d);
+    r.setDebug(true);
+    r.render(); r.render();
+    fs.writeFileSync('%(out)s.' + debugView, Buffer.from(r.readAccum().buffer));
+    fs.writeFileSync('%(out)s.ids.' + debugView, Buffer.from(r.readIds().buffer));
+    r.destroy();
+  }
+  console.log('ok');
+})();
+""" % dict(js=JS, w=width, h=height, spp=spp, scene=S.scene_path("boxes"), out=str(tmp_path / "dbg"))
+    assert node(script).strip().endswith("ok")
+    for flag in (True, False):
+        orc = O.OracleRenderer(scenes["boxes"], width, height, debug_view=flag)
+        orc.debug_enabled = True
+        orc.set_samples_per_pixel(spp)
+        orc.render_frames(2)
+        acc = np.fromfile(str(tmp_path / "dbg") + "." + ("true" if flag else "false"), np.float32).reshape(height, width, 3)
+        ids = np.fromfile(str(tmp_path / "dbg") + ".ids." + ("true" if flag else "false"), np.int32).reshape(height, width)
+        assert np.array_equal(ids, orc.ids)
+        assert np.array_equal(acc, orc.accum_rgb())
+        assert bool((ids >= 1 + 34).any()) == flag

@@ -76,3 +76,32 @@ def _frames_agree(sc, width, height, frames, spp, sphere_lights=False):
         assert np.array_equal(frame, orc.frame_f16)
     assert np.array_equal(accum, orc.accum)
     assert rays == int(orc.counters[0])
+
+
+def test_debug_view_extension_c_vs_numpy(scenes):
+    """The opt-in debug view (ray_triangle_normal_intersect markers in ray_all while debugEnabled is set):
+    both restatements agree bit for bit, the markers show up, and the uniform alone changes nothing."""
+    scene = scenes["boxes"]
+    width, height, spp = 24, 14, 2
+    sp, tr = S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles)
+    orc = O.OracleRenderer(scene, width, height, debug_view=True)
+    orc.debug_enabled = True
+    orc.set_samples_per_pixel(spp)
+    orc.render()
+    acc = np.zeros((3, height, width), np.float32)
+    frame, ids, rays = N.render_frame(S.pack_uniforms(scene.camera, 1, width, height, spp, True), sp, tr, acc, debug_view=True)
+    assert np.array_equal(ids, orc.ids)
+    assert np.array_equal(frame, orc.frame_f16)
+    assert np.array_equal(acc, orc.accum)
+    assert rays == int(orc.counters[0])
+    assert (orc.ids >= len(sp) + len(tr)).any(), "no marker visible: the test scene does not exercise the extension"
+    # extension off: the uniform is ignored, as the reference's shader ignores it
+    plain = O.OracleRenderer(scene, width, height)
+    plain.set_samples_per_pixel(spp)
+    plain.render()
+    ignored = O.OracleRenderer(scene, width, height)
+    ignored.debug_enabled = True
+    ignored.set_samples_per_pixel(spp)
+    ignored.render()
+    assert np.array_equal(plain.accum, ignored.accum) and np.array_equal(plain.ids, ignored.ids)
+    assert not np.array_equal(plain.ids, orc.ids)
