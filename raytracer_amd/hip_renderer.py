@@ -40,7 +40,8 @@ class HipRenderer:
     @classmethod
     def create(cls, width: int, height: int, scene_path: str, device: int = 0, stripe_rows: int = 8,
                stripe_index: int = 0, stripe_count: int = 1, max_bounces: int = 6,
-               sphere_lights: bool = False, apply_model_transforms: bool = False) -> Optional["HipRenderer"]:
+               sphere_lights: bool = False, apply_model_transforms: bool = False,
+               debug_view: bool = False) -> Optional["HipRenderer"]:
         """``WebGPURenderer.Create`` (src/webgpu-renderer.ts:48-103): every
         failure is reported and ``None`` is returned; it never raises."""
         renderer = cls(width, height)
@@ -49,6 +50,7 @@ class HipRenderer:
                 renderer.ctx = capi.Context(width, height, device, stripe_rows, stripe_index, stripe_count)
                 renderer.ctx.set_max_bounces(max_bounces)
                 renderer.ctx.set_sphere_lights(sphere_lights)
+                renderer.ctx.set_debug_view(debug_view)   # opt-in: set_debug(True) then draws the triangles' normal markers
             except Exception as e:  # "Failed to create pipelines"
                 raise RuntimeError("Failed to create pipelines: %s" % e)
             try:

@@ -7,7 +7,12 @@
  *
  *   node cli.js --scene scene.json --width 640 --height 360 --spp 16 --frames 4
  *               [--bounces 6] [--image out.png | --ppm out.ppm] [--preview-every k]
- *               [--apply-model-transforms] [--sphere-lights] [--dump prefix] [--per-frame]
+ *               [--apply-model-transforms] [--sphere-lights] [--debug-view] [--dump prefix] [--per-frame]
+ *               [--devices 0,1,...]
+ *
+ * --debug-view draws every triangle's normal marker (the shader's unused debug helper).
+ * --devices renders with one renderer per listed GPU, image rows dealt to them in 8-row stripes
+ * (multi-gpu.js), and writes the assembled image / accumulator.
  *
  * --preview-every k rewrites the image file after every k frames (progressive preview).
  */
@@ -22,6 +27,7 @@ function parseArgs(argv) {
         if (k === '--per-frame') { a.perFrame = true; continue; }
         if (k === '--apply-model-transforms') { a.applyModelTransforms = true; continue; }
         if (k === '--sphere-lights') { a.sphereLights = true; continue; }
+        if (k === '--debug-view') { a.debugView = true; continue; }
         const v = argv[++i];
         if (k === '--scene') a.scene = v;
         else if (k === '--width') a.width = parseInt(v, 10);
@@ -32,21 +38,43 @@ function parseArgs(argv) {
         else if (k === '--ppm' || k === '--image') a.ppm = v;
         else if (k === '--preview-every') a.previewEvery = parseInt(v, 10);
         else if (k === '--dump') a.dump = v;
+        else if (k === '--devices') a.devices = v.split(',').map((x) => parseInt(x, 10));
         else throw new Error('unknown argument ' + k);
     }
     if (!a.scene) throw new Error('--scene is required');
     return a;
 }
 
+// several GPUs: rows dealt to one renderer per device, assembled on the first
+async function mainSplit(a) {
+    const { renderSplit } = require('./multi-gpu');
+    const r = await renderSplit(a.scene, { width: a.width, height: a.height, spp: a.spp, frames: a.frames, devices: a.devices,
+                                            maxBounces: a.bounces });
+    if (a.ppm) {
+        const pixels = new Uint8Array(a.width * a.height * 4);
+        for (let i = 0; i < a.width * a.height; i++) {
+            for (let c = 0; c < 3; c++) pixels[4 * i + c] = Math.floor(r.accum[3 * i + c] * 255 + 0.5); // 8-bit unorm, no gamma
+            pixels[4 * i + 3] = 255;
+        }
+        writeImage(a.ppm, pixels, a.width, a.height);
+    }
+    if (a.dump) fs.writeFileSync(a.dump + '.accum.f32', Buffer.from(r.accum.buffer));
+    console.log(JSON.stringify({ scene: a.scene, width: a.width, height: a.height, frames: a.frames, spp_per_frame: a.spp,
+                                 devices: a.devices, rays: r.rays, seconds: r.ms / 1e3, mrays_per_s: r.rays / r.ms / 1e3,
+                                 ms_per_frame: r.ms / a.frames }));
+}
+
 async function main() {
     const a = parseArgs(process.argv);
+    if (a.devices && a.devices.length > 1) return mainSplit(a);
     const canvas = { width: a.width, height: a.height, pixels: a.ppm ? new Uint8Array(a.width * a.height * 4) : null };
     // the canvas image is only needed when a file is written: fill it on demand, not on every frame
     const renderer = await HipRenderer.Create(canvas, a.scene, { maxBounces: a.bounces, presentEvery: 1 << 30,
                                                                  applyModelTransforms: a.applyModelTransforms,
-                                                                 sphereLights: a.sphereLights });
+                                                                 sphereLights: a.sphereLights, debugView: a.debugView });
     if (!renderer) process.exit(1);
     renderer.setSamplesPerPixel(a.spp);
+    if (a.debugView) renderer.setDebug(true);
     const t0 = process.hrtime.bigint();
     const present = () => {
         renderer.accumulator.render(null, canvas.pixels);
