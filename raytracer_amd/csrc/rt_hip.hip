@@ -94,13 +94,13 @@ __host__ __device__ inline int stripe_global_row(const StripeMap &m, int local)
 #define RT_PARK2_SLOTS 15
 #endif
 #ifndef RT_LARGE_STACK
-#define RT_LARGE_STACK 16 // large scenes (32-bit links): stack entries in LDS, the rest in global memory
+#define RT_LARGE_STACK 12 // large scenes (32-bit links): stack entries in LDS, the rest in global memory
 #endif
 #ifndef RT_LARGE_SLOTS
 #define RT_LARGE_SLOTS 14
 #endif
 #ifndef RT_LARGE_MINW
-#define RT_LARGE_MINW 5
+#define RT_LARGE_MINW 6
 #endif
 #ifndef RT_PARK2_MINW
 #define RT_PARK2_MINW 6

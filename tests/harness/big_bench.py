@@ -16,6 +16,8 @@ ctx.set_max_bounces(8)
 for k, name_ in enumerate(['SHADE', 'LEAF', 'BPC', 'BATCH', 'SDONE', 'REFILL']):
     if 'RT_' + name_ in os.environ: ctx.set_tuning(k, int(os.environ['RT_' + name_]))
 if 'RT_SHADEWAIT' in os.environ: ctx.set_tuning(10, int(os.environ['RT_SHADEWAIT']))
+if 'RT_MAXLEAF' in os.environ: ctx.set_tuning(6, int(os.environ['RT_MAXLEAF']))
+if 'RT_TRICOST' in os.environ: ctx.set_tuning(7, int(os.environ['RT_TRICOST']))
 t = time.time(); ctx.set_scene(sp, tr); ctx.sync(); t_scene = time.time() - t
 ctx.set_uniforms(S.pack_uniforms(cam, 1, W, H, spp))
 ctx.render_frames(1, 1); ctx.sync()
