@@ -237,14 +237,14 @@ def main():
         ctx.export_owned_rows(local_rows.data_ptr())
         ctx.sync()
         t_render = time.perf_counter() - t0
-        blocks = sharding.all_gather_rows(local_rows.cpu() if rehearse else local_rows, world,
-                                          counts=[len(sharding.owned_rows(HEIGHT, 8, r, world)) for r in range(world)])
+        gathered, counts = sharding.all_gather_rows_padded(
+            local_rows.cpu() if rehearse else local_rows, world,
+            counts=[len(sharding.owned_rows(HEIGHT, 8, r, world)) for r in range(world)])
         if rank == 0:
-            for src, block in enumerate(blocks):
-                if src != 0:
-                    block = block.cuda().contiguous()
-                    torch.cuda.synchronize()
-                    ctx.import_rows(block.data_ptr(), src)
+            # one call scatters every other rank's block into the planes (rank 0's own rows are in place)
+            gathered = gathered.cuda().contiguous()
+            torch.cuda.synchronize()
+            ctx.import_gathered_rows(gathered.data_ptr(), max(counts), 0)
             ctx.sync()
     barrier()
     dt = time.perf_counter() - t0

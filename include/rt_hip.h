@@ -283,6 +283,12 @@ int rt_take_triangle_tests(rt_context *ctx, uint32_t *triangle_tests);
 int rt_owned_rows(rt_context *ctx, int *rows);
 int rt_export_owned_rows(rt_context *ctx, void *dst_device);
 int rt_import_rows(rt_context *ctx, const void *src_device, int from_index);
+/* rt_import_gathered_rows: the result of an all-gather in one call: `src_device` holds one block per
+ * stripe index, in index order, each padded to rows_per_block rows (3 planes of rows_per_block*width
+ * float32; the rows beyond a stripe's own count are ignored); every block except that of
+ * `skip_index` (pass -1 for none; usually the caller's own index, whose rows are in place) is
+ * scattered into this context's accumulator planes, on the context's stream. */
+int rt_import_gathered_rows(rt_context *ctx, const void *src_device, int rows_per_block, int skip_index);
 /* The same exchange through host memory, for hosts that have no device buffers of their own (the
  * Node addon): rt_read_owned_rows waits for the context and fills `planes` with 3*owned_rows*width
  * float32 in the layout above; rt_write_rows scatters such a block that came from the context with

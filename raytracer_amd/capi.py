@@ -51,6 +51,7 @@ SYMBOLS = {
     "rt_owned_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "rt_export_owned_rows": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_import_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "rt_import_gathered_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "rt_read_owned_rows": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_rows_of_stripe": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "rt_write_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
@@ -215,6 +216,9 @@ class Context:
 
     def import_rows(self, device_ptr: int, from_index: int):
         _check(self.lib.rt_import_rows(self.handle, C.c_void_p(device_ptr), from_index))
+
+    def import_gathered_rows(self, device_ptr: int, rows_per_block: int, skip_index: int = -1):
+        _check(self.lib.rt_import_gathered_rows(self.handle, C.c_void_p(device_ptr), rows_per_block, skip_index))
 
     def rows_of_stripe(self, stripe_index: int) -> int:
         v = C.c_int()

@@ -568,7 +568,9 @@ __global__ void export_rows_kernel(const float *accum, float *dst, int width, in
     for (int c = 0; c < 3; c++) dst[c * n + i] = accum[c * plane + (size_t)y * width + x];
 }
 
-__global__ void import_rows_kernel(float *accum, const float *src, int width, int height, int local_rows, StripeMap sm)
+// src_plane: elements between the planes of the block (local_rows * width when the block is dense)
+__global__ void import_rows_kernel(float *accum, const float *src, int width, int height, int local_rows, StripeMap sm,
+                                   size_t src_plane)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t n = (size_t)local_rows * width;
@@ -576,7 +578,7 @@ __global__ void import_rows_kernel(float *accum, const float *src, int width, in
     int ly = (int)(i / width), x = (int)(i % width);
     int y = stripe_global_row(sm, ly);
     size_t plane = (size_t)width * height;
-    for (int c = 0; c < 3; c++) accum[c * plane + (size_t)y * width + x] = src[c * n + i];
+    for (int c = 0; c < 3; c++) accum[c * plane + (size_t)y * width + x] = src[c * src_plane + i];
 }
 
 int owned_rows_of(int height, const StripeMap &m)
@@ -1453,8 +1455,34 @@ int rt_import_rows(rt_context *c, const void *src_device, int from_index)
     size_t n = (size_t)rows * c->width;
     if (n == 0) return RT_OK;
     hipLaunchKernelGGL(import_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->fb.accum,
-                       (const float *)src_device, c->width, c->height, rows, sm);
+                       (const float *)src_device, c->width, c->height, rows, sm, n);
     RT_HIP_CHECK(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_import_gathered_rows(rt_context *c, const void *src_device, int rows_per_block, int skip_index)
+{
+    if (!c || !src_device) return fail(RT_ERR_INVALID, "null argument");
+    RT_FLUSH_PENDING(c);
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    for (int from = 0; from < c->sm.count; from++) { // nothing is written unless every block fits
+        StripeMap sm = c->sm;
+        sm.index = from;
+        if (from != skip_index && owned_rows_of(c->height, sm) > rows_per_block)
+            return fail(RT_ERR_INVALID, "rows_per_block is smaller than a stripe's block");
+    }
+    for (int from = 0; from < c->sm.count; from++) {
+        if (from == skip_index) continue;
+        StripeMap sm = c->sm;
+        sm.index = from;
+        int rows = owned_rows_of(c->height, sm);
+        size_t n = (size_t)rows * c->width, block = (size_t)3 * rows_per_block * c->width;
+        if (n == 0) continue;
+        hipLaunchKernelGGL(import_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->fb.accum,
+                           (const float *)src_device + (size_t)from * block, c->width, c->height, rows, sm,
+                           (size_t)rows_per_block * c->width);
+        RT_HIP_CHECK(hipGetLastError());
+    }
     return RT_OK;
 }
 

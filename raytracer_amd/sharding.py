@@ -31,14 +31,15 @@ def owned_rows(height: int, stripe_rows: int, index: int, count: int) -> np.ndar
     return y[(y // stripe_rows) % count == index]
 
 
-def all_gather_rows(local_block, world: int, counts=None):
-    """All-gather of per-rank row blocks of different heights.
+def all_gather_rows_padded(local_block, world: int, counts=None):
+    """All-gather of per-rank row blocks of different heights, in one collective.
 
     local_block: torch tensor (3, rows_r, width) on the device the process group
-    communicates on (CUDA for RCCL, CPU for gloo).  Returns the list of blocks of
-    all ranks.  counts: rows per rank when the caller knows them (owned_rows gives
-    them without communication); otherwise one extra collective exchanges them.
-    The payload goes in one collective, padded to the tallest block."""
+    communicates on (CUDA for RCCL, CPU for gloo).  Returns (gathered, counts):
+    gathered is one tensor (world, 3, tallest, width), block r padded with zero rows
+    to the tallest block (the layout rt_import_gathered_rows takes), counts the rows
+    per rank.  counts: rows per rank when the caller knows them (owned_rows gives
+    them without communication); otherwise one extra collective exchanges them."""
     import torch
     import torch.distributed as dist
 
@@ -55,6 +56,12 @@ def all_gather_rows(local_block, world: int, counts=None):
         padded[:, : local_block.shape[1]] = local_block
     out = torch.empty((world,) + tuple(padded.shape), dtype=padded.dtype, device=padded.device)
     dist.all_gather(list(out.unbind(0)), padded)   # views of one buffer: the collective writes in place
+    return out, counts
+
+
+def all_gather_rows(local_block, world: int, counts=None):
+    """all_gather_rows_padded, returned as the list of the ranks' dense blocks."""
+    out, counts = all_gather_rows_padded(local_block, world, counts)
     return [out[r, :, :n].contiguous() for r, n in enumerate(counts)]
 
 

@@ -71,3 +71,36 @@ def test_full_size_bvh_vs_brute_force_and_oracle_band(scenes, name, width, heigh
     compare("frames 2..%d" % (1 + batched))
     bvh.close()
     brute.close()
+
+
+@pytest.mark.parametrize("which", ["heightfield_131k", "suzanne_split_5x_991k"])
+def test_full_size_large_scenes_two_traversals_agree(which):
+    """BASELINE config (e) (991,246 triangles, 8 bounces) and the 131,086-triangle height field at
+    1920x1080 x 16 spp: the brute-force kernels cannot finish these, so the two independent BVH
+    traversals are compared on the whole frame: the persistent kernel (4-wide tree, per-lane state
+    machine, LDS stack with its overflow area) against the one-thread-per-pixel kernel (binary tree,
+    the shader's loop nest).  The small-image tests tie each of them to the oracle on these scenes."""
+    if which == "heightfield_131k":
+        from tests.synth import heightfield_scene
+
+        sc = heightfield_scene(256)
+        camera, spheres, tris = sc.camera, S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles)
+    else:
+        camera, spheres, tris = S.subdivided_suzanne_packed(5)
+    width, height, spp = 1920, 1080, 16
+    out = {}
+    for mode in (capi.RT_MODE_BVH, capi.RT_MODE_BVH_TILES):
+        ctx = capi.Context(width, height)
+        ctx.set_mode(mode)
+        ctx.set_max_bounces(8)
+        ctx.set_scene(spheres, tris)
+        ctx.set_uniforms(S.pack_uniforms(camera, 1, width, height, spp))
+        ctx.render_frame()
+        ctx.render_frames(2, 2)
+        out[mode] = (ctx.read_primary_ids(), ctx.read_frame_f16(), ctx.read_accum(), int(ctx.read_counters()[0]))
+        ctx.close()
+    a, b = out[capi.RT_MODE_BVH], out[capi.RT_MODE_BVH_TILES]
+    assert np.array_equal(a[0], b[0])
+    assert _f16_equal(a[1], b[1])
+    assert np.array_equal(a[2], b[2])
+    assert a[3] == b[3]

@@ -124,3 +124,34 @@ def test_striped_frame_sums(scenes):
         own = sharding.owned_rows(height, 8, index, count)
         assert np.array_equal(ctx.read_accum()[own], ref[own], equal_nan=True)
         ctx.close()
+
+
+def test_import_of_a_gathered_buffer(scenes):
+    """rt_import_gathered_rows: the padded all-gather result (one block per stripe index, each padded to
+    the tallest) scattered by one call, as bench.py's rank 0 does."""
+    import torch
+
+    scene = scenes["boxes"]
+    width, height, count, spp = 100, 61, 3, 2      # 61 rows in 8-row stripes: blocks of 24, 21 and 16 rows
+    orc = O.OracleRenderer(scene, width, height)
+    orc.set_samples_per_pixel(spp)
+    orc.render_frames(2)
+    spheres, tris = S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles)
+    counts = [len(sharding.owned_rows(height, 8, i, count)) for i in range(count)]
+    tallest = max(counts)
+    gathered = torch.full((count, 3, tallest, width), 9.0, dtype=torch.float32, device="cuda")
+    ctxs = []
+    for i in range(count):
+        ctx = capi.Context(width, height, stripe_rows=8, stripe_index=i, stripe_count=count)
+        ctx.set_scene(spheres, tris)
+        ctx.set_uniforms(S.pack_uniforms(scene.camera, 1, width, height, spp))
+        ctx.render_frames(1, 2)
+        gathered[i, :, : counts[i]] = torch.from_numpy(ctx.read_owned_rows()).cuda()
+        ctxs.append(ctx)
+    torch.cuda.synchronize()
+    ctxs[1].import_gathered_rows(gathered.data_ptr(), tallest, 1)     # assembled on the middle rank, its own block skipped
+    assert np.array_equal(ctxs[1].read_accum(), orc.accum_rgb())
+    with pytest.raises(capi.RtError):
+        ctxs[1].import_gathered_rows(gathered.data_ptr(), tallest - 1, 1)     # block 0 has `tallest` rows
+    for ctx in ctxs:
+        ctx.close()
