@@ -24,6 +24,7 @@
 // flight, so results do not depend on how lanes are scheduled.
 #pragma once
 
+#include <type_traits>
 #include "rt_core.h"
 
 #ifndef RT_WIDE_BVH
@@ -122,6 +123,20 @@ RT_HD int32_t lane_primary_id(const Park &park)
 
 RT_HD bool link_is_inner(int32_t cur) { return cur >= 0 && cur != kNoRoot; }
 RT_HD bool link_is_leaf(int32_t cur) { return cur < 0; }
+
+// Whether a stack type asks lane_step_triangle to touch the record its top entry points at
+// (Stack::kTouchesTop, with top_in_lds() and top()).
+template <class T, class = void>
+struct stack_touches_top : std::false_type {};
+template <class T>
+struct stack_touches_top<T, std::void_t<decltype(T::kTouchesTop)>> : std::integral_constant<bool, T::kTouchesTop> {};
+
+// Address of the record a link points at: a 4-wide node or the first triangle of a leaf.
+RT_HD const char *link_address(const SceneView &sc, int32_t link)
+{
+    return link >= 0 ? (const char *)sc.nodes4 + ((size_t)link << 7)
+                     : (const char *)(sc.tri_isect + kTriRecord * (size_t)((uint32_t)~link >> 3));
+}
 
 template <class Stack>
 RT_HD void lane_pop(Lane &L, Stack &stack)
@@ -312,6 +327,11 @@ RT_HD void lane_step_triangle(const SceneView &sc, Lane &L, Stack &stack, TestCo
     uint32_t first = code >> 3, left = code & 7u; // triangles after this one
     const f4 *tr = sc.tri_isect + kTriRecord * (size_t)first;
     f4 a = tr[0], b = tr[1], c = tr[2];
+    float touched = 0.0f;
+    if constexpr (stack_touches_top<Stack>::value) {
+        // what the lane visits after this leaf is known already: start bringing it into the caches
+        if (left == 0u && stack.top_in_lds()) touched = *(const float *)link_address(sc, stack.top());
+    }
     float t = triangle_t(L.o, L.d, xyz(a), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x));
     if (cnt) cnt->tris++;
     bool stop = false;
@@ -328,6 +348,11 @@ RT_HD void lane_step_triangle(const SceneView &sc, Lane &L, Stack &stack, TestCo
                 else L.tmax = t;
             }
         }
+    }
+    if constexpr (stack_touches_top<Stack>::value) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" ::"v"(touched)); // keeps the load
+#endif
     }
     if (stop) { L.cur = kNoRoot; L.mode = kLaneShadowDone; }
     else if (left != 0u) L.cur = (int32_t)~(((first + 1u) << 3) | (left - 1u));
