@@ -331,6 +331,7 @@ def main():
         except Exception:
             traffic = None
     valu = None
+    l1 = None
     calib = os.path.join(ROOT, "profiles", "valu_calibration.json")
     if os.path.exists(calib) and world == 1:
         try:
@@ -340,6 +341,10 @@ def main():
                 valu = {"valu_insts_per_simd_cycle": k["valu_insts_per_simd_cycle"], "ceiling_plain_fma": rec["ceiling_plain_fma"],
                         "frac_of_ceiling": k["valu_insts_per_simd_cycle"] / rec["ceiling_plain_fma"],
                         "lanes_active_per_valu_inst": k["lanes_active_per_valu_inst"], "source": rec.get("source", "")}
+                if "l1_access_ceiling_per_cu_cycle" in rec and "l1_accesses_per_cu_cycle" in k:
+                    l1 = {"accesses_per_cu_cycle": k["l1_accesses_per_cu_cycle"], "ceiling": rec["l1_access_ceiling_per_cu_cycle"],
+                          "frac_of_ceiling": k["l1_accesses_per_cu_cycle"] / rec["l1_access_ceiling_per_cu_cycle"],
+                          "accesses_per_ray": k.get("l1_accesses_per_ray"), "source": rec.get("l1_access_ceiling_source", "")}
         except Exception:
             valu = None
 
@@ -394,6 +399,7 @@ def main():
                         "sphere_tests": c_sph / c_rays, "bounces": c_bounces / c_rays},
             "lane_utilisation": lane_util,
             "valu_issue": valu,
+            "l1_access": l1,
             "brute_force_equivalent": {"flops_per_ray": brute_flops_per_ray,
                                        "tflops": brute_flops_per_ray * rays_per_launch / (launch_ms * 1e-3) / 1e12},
         },

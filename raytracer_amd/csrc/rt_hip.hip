@@ -81,6 +81,9 @@ __host__ __device__ inline int stripe_global_row(const StripeMap &m, int local)
 #ifndef RT_XCC_ID_QUEUE
 #define RT_XCC_ID_QUEUE 0 // 1: a wave's first work queue is chosen by the XCC_ID hardware register instead of blockIdx % 8
 #endif
+#ifndef RT_PACKED_LINKS
+#define RT_PACKED_LINKS 1 // small scenes: child links read from the low bytes of the node planes, no link vector fetch
+#endif
 #ifndef RT_TOUCH_TOP
 #define RT_TOUCH_TOP 1
 #endif
@@ -147,9 +150,13 @@ struct LdsStack {
 //          below 128 (at exactly 32 KB only four blocks fit)
 //   LINK16 links fit 16 bits (scenes of <= 4096 triangles): 2-byte stack entries
 //   SPILL  stack entries beyond STACK go to global memory (deep trees of large scenes)
-template <int STACK_, int PARK_, int MINW_, bool LINK16_, bool SPILL_>
+//   PLANE_LINKS  16: a node's child links are read from the low bytes of its x and y planes, where the
+//          builder also writes them when they fit 16 bits (BuiltScene::links_packed), instead of from
+//          its link vector: six loads per node visit instead of seven (-1.4 % on suzanne, -2.1 % on
+//          boxes; the same with 24-bit links for large scenes measured no gain).  Follows LINK16.
+template <int STACK_, int PARK_, int MINW_, bool LINK16_, bool SPILL_, int PLANE_LINKS_ = (LINK16_ && RT_PACKED_LINKS) ? 16 : 0>
 struct LaneCfg {
-    static constexpr int STACK = STACK_, PARK = PARK_, MINW = MINW_;
+    static constexpr int STACK = STACK_, PARK = PARK_, MINW = MINW_, PLANE_LINKS = PLANE_LINKS_;
     static constexpr bool LINK16 = LINK16_, SPILL = SPILL_;
 };
 constexpr int kSpillEntries = 64 - RT_LARGE_STACK; // trees whose traversal needs up to 64 entries
@@ -441,7 +448,7 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
                 occ_dead += __popcll(__ballot(L.mode == rt::kLaneDead));
             }
             if (COUNT) { int n_in = __popcll(__ballot(inner)); if (n_in) { ph_inner_it++; ph_inner_ln += n_in; } tc0 = clock64(); }
-            if (inner) rt::lane_step_node(sc, L, stack, cp);
+            if (inner) rt::lane_step_node<CFG::PLANE_LINKS>(sc, L, stack, cp);
             if (COUNT) tc_inner += clock64() - tc0;
 
             bool leaf = L.mode == rt::kLaneTraverse && rt::link_is_leaf(L.cur);
@@ -727,6 +734,8 @@ template <class CFG, bool COUNT, bool FUSED>
 int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchParams &bp, unsigned int *counter, hipStream_t stream)
 {
     auto kernel = render_persistent_kernel<CFG, COUNT, FUSED>;
+    if (CFG::PLANE_LINKS != 0 && c->host_scene.links_packed != CFG::PLANE_LINKS)
+        return fail(RT_ERR_UNSUPPORTED, "internal: kernel variant and node link packing do not match");
     int per_cu = c->tune_blocks_per_cu;
     if (per_cu <= 0) {
         RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
@@ -788,7 +797,8 @@ int launch_persistent_d(rt_context *c, const rt::FrameParams &fp, const BatchPar
     if (c->tune_lds_state == 0 || !rt::kWideBvh) return launch_persistent_t<CfgRegisters, COUNT, FUSED>(c, fp, bp, counter, stream);
     // 16-bit links: node indices below 32768 and leaf codes (first << 3 | count - 1) below 32768
     const rt::BuiltScene &hs = c->host_scene;
-    bool small = hs.n_tris <= 4096 && hs.nodes.size() / 4 < 32768 && hs.nodes4.size() / 8 < 32768 && depth <= 32;
+    bool small = hs.n_tris <= 4096 && hs.nodes.size() / 4 < 32768 && hs.nodes4.size() / 8 < 32768 && depth <= 32 &&
+                 (hs.links_packed == 16 || !RT_PACKED_LINKS);
     if (small) {
         if (depth <= (uint32_t)CfgSmall::STACK && c->tune_lds_state >= 2) return launch_persistent_t<CfgSmall, COUNT, FUSED>(c, fp, bp, counter, stream);
         return launch_persistent_t<CfgSmallDeep, COUNT, FUSED>(c, fp, bp, counter, stream);

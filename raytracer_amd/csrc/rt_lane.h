@@ -249,13 +249,16 @@ RT_HD void fma4(const f4 &a, float m, float s, float out[4])
 // The second half of a 4-wide node visit: given the entry distances tn[] and hit flags h[] of the
 // four children and their links, the nearest hit child is visited next and the other hit children
 // go on the stack.
-template <class Stack>
+// LINKS16: the links are 16-bit codes in the low halves of lk (0x7fff marks an unused slot); the
+// stack takes the low 16 bits of what is pushed, the link visited next is sign-extended.
+template <int LINKS = 0, class Stack>
 RT_HD void lane_descend4(Lane &L, Stack &stack, const float tn[4], const bool h[4], f4 lk, TestCounts *cnt)
 {
     float t0 = tn[0], t1 = tn[1], t2 = tn[2], t3 = tn[3];
     int32_t c0 = (int32_t)f2u(lk.x), c1 = (int32_t)f2u(lk.y), c2 = (int32_t)f2u(lk.z), c3 = (int32_t)f2u(lk.w);
-    // children 0 and 1 always exist; an unused slot (link kNoRoot) is never a hit whatever its box says
-    bool h0 = h[0], h1 = h[1], h2 = h[2] & (c2 != kNoRoot), h3 = h[3] & (c3 != kNoRoot);
+    constexpr int32_t unused = LINKS == 16 ? 0x7fff : kNoRoot;
+    // children 0 and 1 always exist; an unused slot is never a hit whatever its box says
+    bool h0 = h[0], h1 = h[1], h2 = h[2] & (c2 != unused), h3 = h[3] & (c3 != unused);
     if (cnt) cnt->boxes += 2; // counted in box pairs
     // nearest hit child
     float tb = INFINITY;
@@ -270,7 +273,7 @@ RT_HD void lane_descend4(Lane &L, Stack &stack, const float tn[4], const bool h[
     if (h1 && which != 1) stack.push(c1);
     if (h2 && which != 2) stack.push(c2);
     if (h3 && which != 3) stack.push(c3);
-    L.cur = next;
+    L.cur = LINKS == 16 ? (int32_t)(int16_t)next : next;
 }
 
 // One visit of a 4-wide node: four slab tests, the nearest hit child is visited
@@ -280,7 +283,19 @@ RT_HD void lane_descend4(Lane &L, Stack &stack, const float tn[4], const bool h[
 // the near and far planes are fetched as such (a node stores lo.x[4], lo.y[4],
 // lo.z[4], hi.x[4], hi.y[4], hi.z[4]) and no per-slab min/max is needed; for lo <= hi
 // this gives the same distances as slab().
-template <class Stack>
+// bits 0-7 of lo, bits 0-7 of hi as bits 8-15: a 16-bit link from the low bytes of two plane values
+RT_HD float link16_of(float lo, float hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return u2f(__builtin_amdgcn_perm(f2u(hi), f2u(lo), 0x0c0c0400u));
+#else
+    return u2f(((f2u(hi) & 0xffu) << 8) | (f2u(lo) & 0xffu));
+#endif
+}
+
+// PACKED: the node's links are read from the low bytes of its x and y planes (BuiltScene::links_packed)
+// instead of from the link vector: six loads per visit instead of seven.
+template <int PACKED = 0, class Stack>
 RT_HD void lane_visit4(const char *node, uint32_t at, Lane &L, Stack &stack, TestCounts *cnt)
 {
     // byte offset of the near plane vector: lo (0/16/32) for a non-negative direction, hi (48/64/80) otherwise
@@ -290,7 +305,9 @@ RT_HD void lane_visit4(const char *node, uint32_t at, Lane &L, Stack &stack, Tes
     f4 nearx = *(const f4 *)(node + nx), farx = *(const f4 *)(node + (nx ^ 48u));
     f4 neary = *(const f4 *)(node + ny), fary = *(const f4 *)(node + (ny ^ 80u));
     f4 nearz = *(const f4 *)(node + nz), farz = *(const f4 *)(node + (nz ^ 112u));
-    f4 lk = *(const f4 *)(node + (at | 96u));
+    f4 lk;
+    if (PACKED == 16) lk = mk4(link16_of(nearx.x, neary.x), link16_of(nearx.y, neary.y), link16_of(nearx.z, neary.z), link16_of(nearx.w, neary.w));
+    else lk = *(const f4 *)(node + (at | 96u));
     float ax[4], ay[4], az[4], bx[4], by[4], bz[4], tn[4];
     fma4(nearx, L.rb.inv.x, L.rb.ood.x, ax); fma4(farx, L.rb.inv.x, L.rb.ood.x, bx);
     fma4(neary, L.rb.inv.y, L.rb.ood.y, ay); fma4(fary, L.rb.inv.y, L.rb.ood.y, by);
@@ -301,21 +318,21 @@ RT_HD void lane_visit4(const char *node, uint32_t at, Lane &L, Stack &stack, Tes
         float tf = fminf(fminf(bx[i], by[i]), fminf(bz[i], L.tmax));
         h[i] = tn[i] <= tf;
     }
-    lane_descend4(L, stack, tn, h, lk, cnt);
+    lane_descend4<PACKED>(L, stack, tn, h, lk, cnt);
 }
 
 // One visit of the 4-wide node L.cur.
-template <class Stack>
+template <int PACKED = 0, class Stack>
 RT_HD void lane_step_inner4(const SceneView &sc, Lane &L, Stack &stack, TestCounts *cnt)
 {
-    lane_visit4((const char *)sc.nodes4, (uint32_t)L.cur << 7, L, stack, cnt);
+    lane_visit4<PACKED>((const char *)sc.nodes4, (uint32_t)L.cur << 7, L, stack, cnt);
 }
 
 // The node visit of whichever tree the lanes traverse.
-template <class Stack>
+template <int PACKED = 0, class Stack>
 RT_HD void lane_step_node(const SceneView &sc, Lane &L, Stack &stack, TestCounts *cnt)
 {
-    if (kWideBvh) lane_step_inner4(sc, L, stack, cnt);
+    if (kWideBvh) lane_step_inner4<PACKED>(sc, L, stack, cnt);
     else lane_step_inner(sc, L, stack, cnt);
 }
 
@@ -349,9 +366,12 @@ RT_HD void lane_step_triangle(const SceneView &sc, Lane &L, Stack &stack, TestCo
             }
         }
     }
+    (void)touched;
     if constexpr (stack_touches_top<Stack>::value) {
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" ::"v"(touched)); // keeps the load
+#else
+        (void)touched;
 #endif
     }
     if (stop) { L.cur = kNoRoot; L.mode = kLaneShadowDone; }

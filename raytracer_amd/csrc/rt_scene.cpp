@@ -197,6 +197,8 @@ int32_t leaf_link(uint32_t first, uint32_t count) { return (int32_t)~((first << 
 
 } // namespace
 
+void pack_links16(BuiltScene &out);
+
 void build_scene(const void *spheres, uint32_t n_spheres, const void *triangles, uint32_t n_tris,
                  const BuildOptions &opt_in, BuiltScene &out)
 {
@@ -389,6 +391,7 @@ void build_scene(const void *spheres, uint32_t n_spheres, const void *triangles,
         n[6] = mk4(u2f(link[0]), u2f(link[1]), u2f(link[2]), u2f(link[3]));
     }
     out.root4 = 0;
+    pack_links16(out);
     // Deepest the traversal stack can get: every visit may leave up to (children - 1) entries behind.
     std::vector<uint32_t> need(wide.size(), 0);
     for (size_t wi = wide.size(); wi-- > 0;) {
@@ -399,6 +402,57 @@ void build_scene(const void *spheres, uint32_t n_spheres, const void *triangles,
         need[wi] = (uint32_t)(w.n - 1) + below;
     }
     out.max_stack4 = need[0];
+}
+
+namespace {
+// A float with the given low byte that is <= v (down) or >= v (up), as close to v as that allows.
+float with_low_byte(float v, uint32_t byte, bool down)
+{
+    if (!down) return -with_low_byte(-v, byte, true);
+    uint32_t b = f2u(v);
+    if (!(b >> 31)) { // v >= +0: at most v
+        uint32_t c = (b & ~0xffu) | byte;
+        if (c <= b) return u2f(c);
+        if (b >= 0x100u) return u2f(c - 0x100u);
+        return u2f(0x80000000u | byte); // below the smallest positive candidates: the negative value nearest zero
+    }
+    uint32_t m = b & 0x7fffffffu; // v < 0 (or -0): magnitude at least |v|
+    uint32_t c = (m & ~0xffu) | byte;
+    if (c < m) c += 0x100u;
+    return u2f(0x80000000u | c);
+}
+} // namespace
+
+// When every child link of the 4-wide tree fits 16 bits (inner: index < 0x7fff; leaf: the low 16
+// bits of its negative code; unused slot: 0x7fff), the links are also written into the planes the
+// node test loads anyway, so that the kernels for small scenes can skip the fetch of the link
+// vector: the low byte of child k's lo.x and hi.x carries the link's low byte, the low byte of
+// lo.y and hi.y its high byte (whichever of lo / hi a ray reads as the near plane, it finds the
+// byte).  The planes move outwards by at most 2 x 256 ulp (6e-5 of the coordinate), boxes only
+// decide what is visited, and the link vector stays in place for the kernels that read it.
+void pack_links16(BuiltScene &out)
+{
+    out.links_packed = 0;
+    size_t n = out.nodes4.size() / 8;
+    if (n == 0 || n >= 0x7fffu) return;
+    for (size_t i = 0; i < n; i++)
+        for (int k = 0; k < 4; k++) {
+            int32_t link = (int32_t)f2u((&out.nodes4[8 * i + 6].x)[k]);
+            if (link == kNoRoot) continue;
+            if (link >= 0 ? link >= 0x7fff : link < -0x8000) return;
+        }
+    for (size_t i = 0; i < n; i++) {
+        f4 *nd = &out.nodes4[8 * i];
+        for (int k = 0; k < 4; k++) {
+            int32_t link = (int32_t)f2u((&nd[6].x)[k]);
+            uint32_t code = link == kNoRoot ? 0x7fffu : ((uint32_t)link & 0xffffu);
+            (&nd[0].x)[k] = with_low_byte((&nd[0].x)[k], code & 0xffu, true);  // lo.x
+            (&nd[3].x)[k] = with_low_byte((&nd[3].x)[k], code & 0xffu, false); // hi.x
+            (&nd[1].x)[k] = with_low_byte((&nd[1].x)[k], code >> 8, true);     // lo.y
+            (&nd[4].x)[k] = with_low_byte((&nd[4].x)[k], code >> 8, false);    // hi.y
+        }
+    }
+    out.links_packed = 16;
 }
 
 bool make_frame_params(const void *uniforms80, uint32_t max_bounces, FrameParams &fp, std::string &err)

@@ -20,6 +20,9 @@ struct BuiltScene {
     uint32_t max_stack4 = 0; // entries the 4-wide traversal can have on its stack at once
     float coord_mag = 0.0f;  // largest coordinate magnitude of the geometry (triangle vertices, sphere extents)
     float origin_mag = 0.0f; // the BuildOptions::origin_mag the boxes were padded for
+    // The child links of every 4-wide node also ride in the low bytes of its x and y planes (pack_links16
+    // in rt_scene.cpp): true when all links fit 16 bits.
+    int links_packed = 0; // 0 or 16 (bits per link)
 };
 
 struct BuildOptions {

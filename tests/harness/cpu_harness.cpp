@@ -12,10 +12,12 @@
 #include "../../raytracer_amd/csrc/rt_scene.h"
 
 namespace {
+static int g_link_mode = 0; // har_set_link_mode
 struct HostStack {
     int32_t data[128];
     int sp = 0;
-    void push(int32_t v) { data[sp++] = v; if (sp > high) high = sp; }
+    // 16-bit mode: entries are two bytes wide as in the kernels for small scenes (a pop sign-extends)
+    void push(int32_t v) { data[sp++] = g_link_mode == 16 ? (int32_t)(int16_t)v : v; if (sp > high) high = sp; }
     int32_t pop() { return data[--sp]; }
     bool empty() const { return sp == 0; }
     void reset() { sp = 0; }
@@ -26,6 +28,11 @@ struct HostStack {
 static int g_sphere_lights = 0;
 // the opt-in sphere-light extension for the following har_render_frame calls
 extern "C" void har_set_sphere_lights(int enable) { g_sphere_lights = enable; }
+
+// How the lane emulation reads a node's child links: 0 = from the link vector; -1 = as the kernels do
+// for the scene at hand (16-bit links packed into the low bytes of the node planes when the builder
+// says they fit, otherwise the link vector).
+extern "C" void har_set_link_mode(int mode) { g_link_mode = mode; }
 
 extern "C" int har_render_frame(const void *uniforms80, const void *spheres, uint32_t n_spheres,
                                 const void *tris, uint32_t n_tris, uint32_t max_bounces, int brute,
@@ -178,6 +185,11 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
     sc.n_spheres = bs.n_spheres; sc.n_tris = bs.n_tris; sc.n_lights = bs.n_lights;
     sc.n_lights_pass1 = bs.n_lights_pass1; sc.total_power = bs.total_power; sc.root = bs.root;
 
+    const int requested_mode = g_link_mode;
+    const int link_mode = requested_mode < 0 ? bs.links_packed : 0;
+    g_link_mode = link_mode; // what HostStack sees during this call
+    const int32_t n_nodes4 = (int32_t)(bs.nodes4.size() / 8);
+    std::atomic<int> bad_links{0};
     const int W = fp.width, H = fp.height;
     const uint32_t tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8, tiles_per_frame = tiles_x * tiles_y;
     const uint32_t total_tiles = tiles_per_frame * n_frames;
@@ -229,7 +241,11 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
                 if (!n_trav) break;
                 if (n_shade && n_trav * 8 < (n_trav + n_shade) * shade_num) break;
                 for (int i = 0; i < 64; i++)
-                    if (L[i].mode == rt::kLaneTraverse && rt::link_is_inner(L[i].cur)) rt::lane_step_node(sc, L[i], st[i], nullptr);
+                    if (L[i].mode == rt::kLaneTraverse && rt::link_is_inner(L[i].cur)) {
+                        if (L[i].cur >= n_nodes4) { bad_links++; L[i].cur = rt::kNoRoot; L[i].mode = rt::kLaneShadeClosest; continue; }
+                        if (link_mode == 16) rt::lane_step_node<16>(sc, L[i], st[i], nullptr);
+                        else rt::lane_step_node(sc, L[i], st[i], nullptr);
+                    }
                 int n_leaf = 0, n_inner = 0;
                 for (auto &l : L) {
                     n_leaf += l.mode == rt::kLaneTraverse && rt::link_is_leaf(l.cur);
@@ -237,7 +253,11 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
                 }
                 if (n_leaf && (n_leaf >= leaf_lanes || !n_inner))
                     for (int i = 0; i < 64; i++)
-                        if (L[i].mode == rt::kLaneTraverse && rt::link_is_leaf(L[i].cur)) rt::lane_step_triangle(sc, L[i], st[i], nullptr);
+                        if (L[i].mode == rt::kLaneTraverse && rt::link_is_leaf(L[i].cur)) {
+                            uint32_t code = (uint32_t)~L[i].cur;
+                            if ((code >> 3) + (code & 7u) >= bs.n_tris) { bad_links++; L[i].cur = rt::kNoRoot; L[i].mode = rt::kLaneShadeClosest; continue; }
+                            rt::lane_step_triangle(sc, L[i], st[i], nullptr);
+                        }
                 for (int i = 0; i < 64; i++)
                     if (L[i].mode == rt::kLaneShadowDone) rt::lane_shadow_done(sc, fp, L[i], st[i], park[i], n_rays, nullptr);
             }
@@ -275,5 +295,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
         }
     }
     if (counters) { counters[0] += rays; counters[13] += traversed; counters[14] = bs.max_stack4; counters[15] = bs.nodes4.size() / 8; counters[7] = high; }
-    return 0;
+    g_link_mode = requested_mode;
+    if (bad_links) return -2;      // a link led outside the tables
+    return requested_mode < 0 ? link_mode : 0;
 }

@@ -69,6 +69,10 @@ def derived(c, ms, work):
     d["wave_cycles_waiting_for_an_instruction"] = c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]
     d["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
     d["l1_requests_reaching_l2"] = c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"]
+    # the L1 (TCP) takes one access (a 64-byte piece of one line) per clock: its rate against the ceiling that
+    # tests/harness/valu_calib.hip reaches with loads whose lanes all touch different lines
+    d["l1_accesses_per_cu_cycle"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / (cycles * N_CU)
+    d["l1_accesses_per_load_instruction"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / c["TA_TOTAL_WAVEFRONTS_sum"]
     d["ta_busy_frac"] = c["TA_TA_BUSY_sum"] / (cycles * N_CU)
     d["td_busy_frac"] = c["TD_TD_BUSY_sum"] / (cycles * N_CU)
     d["tcp_latency_cycles_per_wave_instruction"] = c["TCP_TCP_LATENCY_sum"] / c["TA_TOTAL_WAVEFRONTS_sum"]
@@ -86,6 +90,7 @@ def derived(c, ms, work):
         d["valu_lane_insts_per_ray"] = c["SQ_THREAD_CYCLES_VALU"] / work["rays_traversed"]  # the counter adds the active lanes of every VALU instruction
         d["hbm_bytes_per_ray"] = (rd + wr) / work["rays_traversed"]
         d["l2_read_requests_per_ray"] = c["TCP_TCC_READ_REQ_sum"] / work["rays_traversed"]
+        d["l1_accesses_per_ray"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / work["rays_traversed"]
     return d
 
 
@@ -125,6 +130,20 @@ if "fma_0_8" in calib["runs"]:
 if "pk_0_8" in calib["runs"]:
     calib["ceiling_packed_fma"] = calib["runs"]["pk_0_8"]["valu_insts_per_simd_cycle"]
 
+# 2b. vector-memory calibration (valu_calib l): clocks per 16-byte load instruction under masks
+vm = dst + "/%s_vmem_calibration.txt" % tag
+if os.path.exists(vm):
+    rows = {}
+    for line in open(vm):
+        m = re.match(r"(contiguous|divergent)\s+(.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s*$", line)
+        if m:
+            rows[(m.group(1), m.group(2), int(m.group(3)))] = float(m.group(5))
+    if ("divergent", "all 64 lanes", 6) in rows:
+        calib["l1_access_ceiling_per_cu_cycle"] = 64.0 / rows[("divergent", "all 64 lanes", 6)]
+        calib["l1_access_ceiling_source"] = ("profiles/%s_vmem_calibration.txt: 64-lane 16-byte loads whose lanes touch 64 different lines, "
+                                             "six waves per SIMD, %.1f CU clocks per instruction" % (tag, rows[("divergent", "all 64 lanes", 6)]))
+        calib["clocks_per_contiguous_load_instruction"] = rows.get(("contiguous", "all 64 lanes", 6))
+
 # 3. PMC summaries
 traffic = {}
 calib["kernel"] = {}
@@ -148,7 +167,9 @@ for key, cfg, out_name in (("pmc_c", "c", "%s_pmc_summary.json" % tag), ("pmc_hf
                         "source": "profiles/%s: FETCH_SIZE x 1024 x 2 (gfx950 tallies 128-byte requests at 64) + WRITE_SIZE x 1024, "
                                   "one %d-frame launch, separate --pmc passes" % (out_name, work["frames"])}
         calib["kernel"][cfg] = {"valu_insts_per_simd_cycle": d["valu_insts_per_simd_cycle"],
-                                "lanes_active_per_valu_inst": d["lanes_active_per_valu_inst"]}
+                                "lanes_active_per_valu_inst": d["lanes_active_per_valu_inst"],
+                                "l1_accesses_per_cu_cycle": d["l1_accesses_per_cu_cycle"],
+                                "l1_accesses_per_ray": d.get("l1_accesses_per_ray")}
     print(key, json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()}))
 json.dump(traffic, open(dst + "/pmc_traffic.json", "w"), indent=1)
 json.dump(calib, open(dst + "/valu_calibration.json", "w"), indent=1)

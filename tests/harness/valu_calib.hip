@@ -27,6 +27,31 @@
 
 constexpr int kFmaPerIter = 32;
 
+// v_fma_mix_f32 reading its first operand as the low or high half of a register (how half-precision
+// node planes would be consumed without conversion instructions), the rest as f32.
+__global__ __launch_bounds__(256) void fma_mix_kernel(float *out, unsigned long long mask, int iters)
+{
+    const int lane = threadIdx.x & 63;
+    float b = 0.999f, c = 1e-3f;
+    unsigned h0 = 0x3c003c01u + threadIdx.x, h1 = 0x3c023c03u, h2 = 0x3c043c05u, h3 = 0x3c063c07u;
+    float r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0;
+    if ((mask >> lane) & 1ull) {
+        for (int i = 0; i < iters; i++) {
+#pragma unroll
+            for (int k = 0; k < kFmaPerIter / 8; k++) {
+                asm volatile("v_fma_mix_f32 %0, %8, %12, %13 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %8, %12, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                             "v_fma_mix_f32 %2, %9, %12, %13 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %3, %9, %12, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                             "v_fma_mix_f32 %4, %10, %12, %13 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %5, %10, %12, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                             "v_fma_mix_f32 %6, %11, %12, %13 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %7, %11, %12, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                             : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3), "=v"(r4), "=v"(r5), "=v"(r6), "=v"(r7)
+                             : "v"(h0), "v"(h1), "v"(h2), "v"(h3), "v"(b), "v"(c));
+            }
+        }
+    }
+    float s = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;
+    if (s == 123.456f) out[0] = s;
+}
+
 template <bool PACKED>
 __global__ __launch_bounds__(256) void fma_kernel(float *out, unsigned long long mask, int iters, unsigned long long *cycles)
 {
@@ -65,8 +90,102 @@ __global__ __launch_bounds__(256) void fma_kernel(float *out, unsigned long long
     if (cycles && lane == (int)__builtin_ctzll(mask) && blockIdx.x == 0 && threadIdx.x < 64) cycles[0] = t1 - t0;
 }
 
+// Vector-memory counterpart: ITER iterations of 8 independent 16-byte loads per lane from a 64 KB
+// table that stays in the L1 (each lane reads its own 16 bytes of a 1 KB row, rows chosen per load),
+// under the same execution masks: whether a load instruction with half of its lanes disabled takes
+// half the time in the address and data units.
+typedef float v4f __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void load_kernel(const v4f *table, float *out, unsigned long long mask, int iters, int spread)
+{
+    const int lane = threadIdx.x & 63;
+    v4f acc = {0, 0, 0, 0};
+    if ((mask >> lane) & 1ull) {
+        // spread 0: lane-contiguous rows (1 KB per load instruction); 1: every lane in a row of its own (divergent, as node fetches are)
+        unsigned idx = spread ? (unsigned)(lane * 61 + threadIdx.x / 64 * 7) : (unsigned)lane;
+        for (int i = 0; i < iters; i++) {
+            v4f v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                unsigned row = (unsigned)(i * 8 + k) & 63u;
+                unsigned at = spread ? ((idx + row * 67u) & 4095u) : (row * 64u + idx);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[k]) : "v"(table + at));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < 8; k++) asm volatile("" ::"v"(v[k]));
+            acc.x += v[0].x;
+        }
+    }
+    if (acc.x == 123.456f) out[0] = acc.x;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 1 && argv[1][0] == 'm') { // "m [iters]": v_fma_mix_f32 issue rate
+        int iters = argc > 2 ? atoi(argv[2]) : 20000;
+        CHECK(hipSetDevice(0));
+        hipDeviceProp_t prop;
+        CHECK(hipGetDeviceProperties(&prop, 0));
+        int cus = prop.multiProcessorCount;
+        double clock_hz = prop.clockRate * 1e3;
+        float *out;
+        CHECK(hipMalloc((void **)&out, 64));
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0));
+        CHECK(hipEventCreate(&e1));
+        for (int wps : {1, 2, 4, 6, 8}) {
+            float ms = 0;
+            for (int rep = 0; rep < 2; rep++) {
+                CHECK(hipEventRecord(e0, 0));
+                hipLaunchKernelGGL(fma_mix_kernel, dim3(cus * wps), dim3(256), 0, 0, out, ~0ull, iters);
+                CHECK(hipEventRecord(e1, 0));
+                CHECK(hipEventSynchronize(e1));
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+            }
+            printf("fma_mix  all 64 lanes  %d waves/SIMD  %.3f ms  %.3f wave-instructions/SIMD/clk\n", wps, ms,
+                   (double)iters * kFmaPerIter * wps / (ms * 1e-3 * clock_hz));
+        }
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 'l') { // "l [iters]": the load kernel
+        int iters = argc > 2 ? atoi(argv[2]) : 4000;
+        CHECK(hipSetDevice(0));
+        hipDeviceProp_t prop;
+        CHECK(hipGetDeviceProperties(&prop, 0));
+        int cus = prop.multiProcessorCount;
+        double clock_hz = prop.clockRate * 1e3;
+        v4f *table;
+        float *out;
+        CHECK(hipMalloc((void **)&table, 4096 * sizeof(v4f)));
+        CHECK(hipMemset(table, 0, 4096 * sizeof(v4f)));
+        CHECK(hipMalloc((void **)&out, 64));
+        unsigned long long every4 = 0;
+        for (int i = 0; i < 64; i += 4) every4 |= 1ull << i;
+        struct M { const char *name; unsigned long long mask; };
+        std::vector<M> masks = {{"all 64 lanes", ~0ull}, {"lanes 0-31", 0xffffffffull}, {"even lanes", 0x5555555555555555ull},
+                                {"lanes 0-15", 0xffffull}, {"every 4th lane", every4}, {"one lane", 1ull}};
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0));
+        CHECK(hipEventCreate(&e1));
+        printf("%-10s %-18s %6s %10s %22s\n", "addresses", "mask", "w/SIMD", "ms", "CU clocks per load inst");
+        for (int spread = 0; spread < 2; spread++)
+            for (const M &m : masks)
+                for (int wps : {2, 6}) {
+                    int blocks = cus * wps;
+                    float ms = 0;
+                    for (int rep = 0; rep < 2; rep++) {
+                        CHECK(hipEventRecord(e0, 0));
+                        hipLaunchKernelGGL(load_kernel, dim3(blocks), dim3(256), 0, 0, table, out, m.mask, iters, spread);
+                        CHECK(hipEventRecord(e1, 0));
+                        CHECK(hipEventSynchronize(e1));
+                        CHECK(hipEventElapsedTime(&ms, e0, e1));
+                    }
+                    double insts_per_cu = (double)iters * 8 * wps * 4; // wave-level load instructions per CU
+                    printf("%-10s %-18s %6d %10.3f %22.2f\n", spread ? "divergent" : "contiguous", m.name, wps, ms,
+                           ms * 1e-3 * clock_hz / insts_per_cu);
+                }
+        return 0;
+    }
     int iters = argc > 1 ? atoi(argv[1]) : 20000;
     // optional filter, for runs under rocprofv3 --pmc: kind (fma | pk), mask number, waves per SIMD
     int only_packed = argc > 2 ? (argv[2][0] == 'p' ? 1 : 0) : -1;

@@ -127,6 +127,28 @@ def test_card_deck_needs_more_than_sixteen_stack_entries():
     assert int(har.counters[7]) > 16 and len(scene.triangles) > 4096
 
 
+@pytest.mark.parametrize("which,expect", [("suzanne", 16), ("boxes", 16), ("card_deck", 0), ("heightfield", 0)])
+def test_links_packed_into_the_node_planes(scenes, which, expect):
+    """The builder writes every 4-wide node's child links into the low bytes of its x and y planes
+    when they fit 16 bits, and the kernels for such scenes read them from there instead of
+    fetching the link vector.  The emulated lanes read the links that way here and must match the
+    oracle (scenes of more than 4096 triangles keep the link vector); the emulation fails if a decoded
+    link leads outside the node or triangle tables."""
+    from tests.synth import card_deck_scene, heightfield_scene
+
+    scene = {"card_deck": lambda: card_deck_scene(3000), "heightfield": lambda: heightfield_scene(48)}.get(
+        which, lambda: scenes[which])()
+    orc = O.OracleRenderer(scene, 40, 23)
+    orc.set_samples_per_pixel(2)
+    orc.render_frames(2)
+    har = HarnessRenderer(scene, 40, 23)
+    assert har.render_frames_lanes(2, 1, 2, packed_links=True) == expect
+    assert np.array_equal(har.ids, orc.ids)
+    assert np.array_equal(har.frame_f16, orc.frame_f16)
+    assert np.array_equal(har.accum, orc.accum)
+    assert int(har.counters[0]) == int(orc.counters[0])
+
+
 @pytest.mark.parametrize("brute", [True, False])
 def test_sphere_light_extension_matches_oracle(brute):
     """The opt-in sampling of emissive spheres (the shader's own sample_light_spheres, which it never
