@@ -16,4 +16,8 @@ for K in "fma 0 8" "fma 1 8" "fma 3 8" "fma 2 8" "pk 0 8" "fma 0 2"; do
   set -- $K
   timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU2 GRBM_GUI_ACTIVE --output-format csv -d $O/calib_$1_$2_$3 -- $R/tests/_build/valu_calib 20000 $1 $2 $3 > $O/calib_$1_$2_$3.log 2>&1 || { echo "calibration pass failed: $K"; exit 1; }
 done
+# vector-memory calibration: clocks per 16-byte load instruction under execution masks, then the L1 counters on the same runs
+timeout -k 10 120 $R/tests/_build/valu_calib l 4000 > $O/vmem_calibration.txt 2>&1 || { echo "load calibration failed"; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TA_TOTAL_WAVEFRONTS_sum TA_TA_BUSY_sum TD_TD_BUSY_sum GRBM_GUI_ACTIVE --output-format csv -d $O/vmem_pmc -- $R/tests/_build/valu_calib l 4000 > $O/vmem_pmc.log 2>&1 || { echo "load calibration counters failed"; exit 1; }
+timeout -k 10 60 $R/tests/_build/valu_calib m 20000 > $O/fma_mix_rate.txt 2>&1 || { echo "fma_mix rate failed"; exit 1; }
 echo profiles done

@@ -130,7 +130,34 @@ if "fma_0_8" in calib["runs"]:
 if "pk_0_8" in calib["runs"]:
     calib["ceiling_packed_fma"] = calib["runs"]["pk_0_8"]["valu_insts_per_simd_cycle"]
 
-# 2b. vector-memory calibration (valu_calib l): clocks per 16-byte load instruction under masks
+# 2b. vector-memory calibration (valu_calib l): clocks per 16-byte load instruction under masks, and the
+# L1 counters of the same runs
+if os.path.exists(src + "/vmem_calibration.txt"):
+    shutil.copy(src + "/vmem_calibration.txt", "%s/%s_vmem_calibration.txt" % (dst, tag))
+if os.path.exists(src + "/fma_mix_rate.txt"):
+    shutil.copy(src + "/fma_mix_rate.txt", "%s/%s_fma_mix_rate.txt" % (dst, tag))
+vmc = glob.glob(src + "/vmem_pmc/*/*_counter_collection.csv")
+if vmc:
+    per = collections.defaultdict(dict)
+    for r in csv.DictReader(open(vmc[0])):
+        per[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
+        per[int(r["Dispatch_Id"])]["grid"] = int(r["Grid_Size"])
+    ds = [d for d in sorted(per) if per[d]["grid"] > 4096]
+    mask_names = ["all 64 lanes", "lanes 0-31", "even lanes", "lanes 0-15", "every 4th lane", "one lane"]
+    runs, i = [], 0
+    for spread in ("contiguous", "divergent"):
+        for mname in mask_names:
+            for wps in (2, 6):
+                c = per[ds[i + 1]]  # the second repetition of each shape
+                i += 2
+                cyc = c["GRBM_GUI_ACTIVE"] / N_XCD
+                runs.append({"addresses": spread, "mask": mname, "waves_per_simd": wps,
+                             "l1_accesses_per_load_instruction": c["TCP_TOTAL_CACHE_ACCESSES_sum"] / c["TA_TOTAL_WAVEFRONTS_sum"],
+                             "l1_accesses_per_cu_cycle": c["TCP_TOTAL_CACHE_ACCESSES_sum"] / (cyc * N_CU),
+                             "ta_busy": c["TA_TA_BUSY_sum"] / (cyc * N_CU), "td_busy": c["TD_TD_BUSY_sum"] / (cyc * N_CU)})
+    json.dump({"source": "tests/_build/valu_calib l 4000 under rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TA_TOTAL_WAVEFRONTS_sum "
+                         "TA_TA_BUSY_sum TD_TD_BUSY_sum GRBM_GUI_ACTIVE: 8 independent 16-byte loads per lane and iteration from a 64 KB table",
+               "runs": runs}, open("%s/%s_vmem_counters.json" % (dst, tag), "w"), indent=1)
 vm = dst + "/%s_vmem_calibration.txt" % tag
 if os.path.exists(vm):
     rows = {}
