@@ -6,6 +6,8 @@
 #include "rt_scene.h"
 
 #include <algorithm>
+#include <array>
+#include <functional>
 #include <cstring>
 #include <limits>
 
@@ -116,7 +118,7 @@ public:
     uint32_t max_depth = 0;
 
 private:
-    static constexpr int kBins = 16;
+    static constexpr int kMaxBins = 64;
 
     bool sah_split(uint32_t first, uint32_t count, const Box &box, const Box &cbox, uint32_t &mid)
     {
@@ -126,8 +128,9 @@ private:
         for (int axis = 0; axis < 3; axis++) {
             float lo = cbox.lo[axis], ext = cbox.hi[axis] - lo;
             if (!(ext > 0.0f)) continue;
-            Box bin_box[kBins];
-            uint32_t bin_n[kBins] = {0};
+            const int kBins = (int)std::min<uint32_t>(std::max<uint32_t>(opt_.bins, 2), kMaxBins);
+            Box bin_box[kMaxBins];
+            uint32_t bin_n[kMaxBins] = {0};
             for (auto &b : bin_box) b.reset();
             float k = (float)kBins / ext;
             for (uint32_t i = first; i < first + count; i++) {
@@ -135,8 +138,8 @@ private:
                 bin_n[b]++;
                 bin_box[b].grow(prims_[i].box);
             }
-            float right_area[kBins];
-            uint32_t right_n[kBins];
+            float right_area[kMaxBins];
+            uint32_t right_n[kMaxBins];
             Box acc;
             acc.reset();
             uint32_t n = 0;
@@ -161,6 +164,7 @@ private:
         if (best_axis < 0) return false;
         float leaf_cost = opt_.triangle_cost * (float)count;
         if (count <= opt_.max_leaf && leaf_cost <= best_cost) return false;
+        const int kBins = (int)std::min<uint32_t>(std::max<uint32_t>(opt_.bins, 2), kMaxBins);
         float lo = cbox.lo[best_axis], ext = cbox.hi[best_axis] - lo;
         float k = (float)kBins / ext;
         auto it = std::partition(prims_.begin() + first, prims_.begin() + first + count, [&](const Prim &p) {
@@ -330,9 +334,8 @@ void build_scene(const void *spheres, uint32_t n_spheres, const void *triangles,
     }
     out.root = link_of(root);
 
-    // 4-wide tree for the persistent kernel: each wide node takes the children of a
-    // binary node and keeps replacing the child of largest surface area by its own
-    // two children until there are four (or only leaves remain).  Node layout
+    // 4-wide tree for the persistent kernel: each wide node takes up to four nodes of the binary
+    // tree below a binary node as its children (see collapse below).  Node layout
     // (8 x f4, 128 bytes): lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] links[4] pad;
     // unused slots (only ever slots 2 and 3) carry the link kNoRoot, which the visit checks.
     if (bn[root].child[0] < 0) {
@@ -341,34 +344,114 @@ void build_scene(const void *spheres, uint32_t n_spheres, const void *triangles,
         return;
     }
     struct Wide { int32_t bin_node; int32_t child[4]; int n; };
-    std::vector<Wide> wide;
-    std::vector<int32_t> wide_of(bn.size(), -1);
-    // breadth-first so that the top of the tree is contiguous in memory
-    std::vector<int32_t> queue{root};
-    for (size_t qi = 0; qi < queue.size(); qi++) {
-        int32_t bi = queue[qi];
-        Wide w;
-        w.bin_node = bi;
-        w.n = 2;
-        w.child[0] = bn[bi].child[0];
-        w.child[1] = bn[bi].child[1];
-        while (w.n < 4) {
-            int best = -1;
-            float best_area = -1.0f;
-            for (int k = 0; k < w.n; k++) {
-                if (bn[w.child[k]].child[0] < 0) continue;
-                float a = bn[w.child[k]].box.half_area();
-                if (a > best_area) { best_area = a; best = k; }
-            }
-            if (best < 0) break;
-            int32_t c = w.child[best];
-            w.child[best] = bn[c].child[0];
-            w.child[w.n++] = bn[c].child[1];
+    // Which binary nodes become the (up to four) children of a wide node: the cut below it that
+    // minimises the expected cost of the wide tree under the surface-area heuristic, by dynamic
+    // programming from the leaves up (binary nodes are numbered parents first).  cost[n][j-1] is the
+    // cheapest way to cover the subtree of n with at most j wide-node child slots; split[n][j-1] is how
+    // many of those slots go to n's left child (0: n itself takes one slot, as a wide node or a leaf).
+    const float c_node = opt.traversal_cost, c_tri = opt.triangle_cost;
+    std::vector<std::array<float, 4>> cost(bn.size());
+    std::vector<std::array<uint8_t, 4>> split(bn.size());
+    for (size_t i = bn.size(); i-- > 0;) {
+        const BuildNode &b = bn[i];
+        float area = b.box.half_area();
+        if (b.child[0] < 0) {
+            for (int j = 0; j < 4; j++) { cost[i][j] = area * c_tri * (float)b.count; split[i][j] = 0; }
+            continue;
         }
-        wide_of[bi] = (int32_t)wide.size();
-        wide.push_back(w);
-        for (int k = 0; k < w.n; k++)
-            if (bn[w.child[k]].child[0] >= 0) queue.push_back(w.child[k]);
+        int32_t l = b.child[0], r = b.child[1];
+        auto distribute = [&](int slots, uint8_t &left_slots) {
+            float best = std::numeric_limits<float>::infinity();
+            for (int k = 1; k < slots; k++) {
+                float c = cost[l][k - 1] + cost[r][slots - k - 1];
+                if (c < best) { best = c; left_slots = (uint8_t)k; }
+            }
+            return best;
+        };
+        uint8_t ls = 1;
+        cost[i][0] = area * c_node + distribute(4, ls); // n as a wide node of its own
+        split[i][0] = 0;
+        for (int j = 2; j <= 4; j++) {
+            uint8_t k = 1;
+            float d = distribute(j, k);
+            if (d < cost[i][j - 2]) { cost[i][j - 1] = d; split[i][j - 1] = k; }
+            else { cost[i][j - 1] = cost[i][j - 2]; split[i][j - 1] = split[i][j - 2]; } // fewer slots are enough
+        }
+    }
+    // the cut of at most `slots` binary nodes below (and possibly including) node n
+    std::function<void(int32_t, int, Wide &)> take = [&](int32_t n, int slots, Wide &w) {
+        uint8_t k = split[n][slots - 1];
+        if (bn[n].child[0] < 0 || k == 0) { w.child[w.n++] = n; return; }
+        take(bn[n].child[0], k, w);
+        take(bn[n].child[1], slots - k, w);
+    };
+    // One collapse of the binary tree: `greedy` keeps replacing the child of largest surface area by
+    // its own two children until there are four (or only leaves remain); otherwise the optimal cut.
+    // Returns the deepest the traversal stack can get: every visit may leave up to (children - 1)
+    // entries behind.
+    auto collapse = [&](bool greedy, std::vector<Wide> &wide, std::vector<int32_t> &wide_of) -> uint32_t {
+        wide.clear();
+        wide_of.assign(bn.size(), -1);
+        // breadth-first so that the top of the tree is contiguous in memory
+        std::vector<int32_t> queue{root};
+        for (size_t qi = 0; qi < queue.size(); qi++) {
+            int32_t bi = queue[qi];
+            Wide w;
+            w.bin_node = bi;
+            w.n = 0;
+            for (int k = 0; k < 4; k++) w.child[k] = -1;
+            if (greedy) {
+                w.n = 2;
+                w.child[0] = bn[bi].child[0];
+                w.child[1] = bn[bi].child[1];
+                while (w.n < 4) {
+                    int best = -1;
+                    float best_area = -1.0f;
+                    for (int k = 0; k < w.n; k++) {
+                        if (bn[w.child[k]].child[0] < 0) continue;
+                        float a = bn[w.child[k]].box.half_area();
+                        if (a > best_area) { best_area = a; best = k; }
+                    }
+                    if (best < 0) break;
+                    int32_t c = w.child[best];
+                    w.child[best] = bn[c].child[0];
+                    w.child[w.n++] = bn[c].child[1];
+                }
+            } else {
+                uint8_t ls = 1;
+                float best = std::numeric_limits<float>::infinity();
+                for (int k = 1; k < 4; k++) {
+                    float c = cost[bn[bi].child[0]][k - 1] + cost[bn[bi].child[1]][4 - k - 1];
+                    if (c < best) { best = c; ls = (uint8_t)k; }
+                }
+                take(bn[bi].child[0], ls, w);
+                take(bn[bi].child[1], 4 - ls, w);
+            }
+            wide_of[bi] = (int32_t)wide.size();
+            wide.push_back(w);
+            for (int k = 0; k < w.n; k++)
+                if (bn[w.child[k]].child[0] >= 0) queue.push_back(w.child[k]);
+        }
+        std::vector<uint32_t> need(wide.size(), 0);
+        for (size_t wi = wide.size(); wi-- > 0;) {
+            const Wide &w = wide[wi];
+            uint32_t below = 0;
+            for (int k = 0; k < w.n; k++)
+                if (bn[w.child[k]].child[0] >= 0) below = std::max(below, need[wide_of[w.child[k]]]);
+            need[wi] = (uint32_t)(w.n - 1) + below;
+        }
+        return need[0];
+    };
+    std::vector<Wide> wide;
+    std::vector<int32_t> wide_of;
+    out.max_stack4 = collapse(opt.greedy_collapse, wide, wide_of);
+    if (!opt.greedy_collapse && out.max_stack4 > opt.prefer_stack) {
+        // the optimal cut tends to be deeper; when that alone takes the tree past the stack of the
+        // fastest kernel variant, the greedy one is the better trade
+        std::vector<Wide> wide_g;
+        std::vector<int32_t> wide_of_g;
+        uint32_t need_g = collapse(true, wide_g, wide_of_g);
+        if (need_g <= opt.prefer_stack) { wide.swap(wide_g); wide_of.swap(wide_of_g); out.max_stack4 = need_g; }
     }
     out.nodes4.assign(wide.size() * 8, mk4(0, 0, 0, 0));
     for (size_t wi = 0; wi < wide.size(); wi++) {
@@ -392,16 +475,6 @@ void build_scene(const void *spheres, uint32_t n_spheres, const void *triangles,
     }
     out.root4 = 0;
     pack_links16(out);
-    // Deepest the traversal stack can get: every visit may leave up to (children - 1) entries behind.
-    std::vector<uint32_t> need(wide.size(), 0);
-    for (size_t wi = wide.size(); wi-- > 0;) {
-        const Wide &w = wide[wi];
-        uint32_t below = 0;
-        for (int k = 0; k < w.n; k++)
-            if (bn[w.child[k]].child[0] >= 0) below = std::max(below, need[wide_of[w.child[k]]]);
-        need[wi] = (uint32_t)(w.n - 1) + below;
-    }
-    out.max_stack4 = need[0];
 }
 
 namespace {

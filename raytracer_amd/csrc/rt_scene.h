@@ -30,6 +30,10 @@ struct BuildOptions {
     uint32_t max_depth = 60;  // deepest leaf allowed (traversal stack bound)
     float traversal_cost = 1.0f;
     float triangle_cost = 1.2f;
+    uint32_t bins = 16;       // bins of the binned surface-area split search (<= 64)
+    bool greedy_collapse = false; // 4-wide tree by expanding the child of largest area instead of the cost-optimal cut
+    // Stack entries of the fastest kernel variant: if only the cost-optimal cut needs more, the greedy one is taken.
+    uint32_t prefer_stack = 22;
     // Largest coordinate magnitude of any ray origin the tree must serve (camera position, scene
     // extent).  The rounding of the box test and of the triangle test's o - v0 grows with it, so
     // boxes are widened in proportion once it exceeds kOriginMagCovered.

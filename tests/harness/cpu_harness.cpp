@@ -3,6 +3,7 @@
 // against the oracle in a container without a GPU.  Test infrastructure only:
 // the shipped library has no CPU rendering path.
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -172,6 +173,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
 {
     rt::BuiltScene bs;
     rt::BuildOptions opt;
+    if (getenv("RT_GREEDY_COLLAPSE")) opt.greedy_collapse = true; // for tests/harness/tree_stats.py
     rt::build_scene(spheres, n_spheres, tris, n_tris, opt, bs);
     float uni[20];
     std::memcpy(uni, uniforms80, 80);
@@ -195,7 +197,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
     const uint32_t total_tiles = tiles_per_frame * n_frames;
     std::vector<uint16_t> batch((size_t)n_frames * W * H * 4);
     std::atomic<uint32_t> work{0};
-    std::atomic<uint64_t> rays{0}, traversed{0}, high{0};
+    std::atomic<uint64_t> rays{0}, traversed{0}, high{0}, sum_boxes{0}, sum_tris{0};
 
     auto wave = [&]() {
         rt::Lane L[64];
@@ -203,6 +205,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
         rt::RegPark park[64];
         for (auto &l : L) l.mode = rt::kLaneNeedUnit;
         rt::RayCounts n_rays = {0, 0};
+        rt::TestCounts cnt = {0, 0, 0, 0};
         uint32_t pool_tile = 0, pool_next = 64;
         bool exhausted = false;
         for (;;) {
@@ -227,7 +230,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
                         L[i].unit = (frame_k * H + py) * W + px; // this emulation numbers units row-major
                         rt::FrameParams f = fp;
                         f.seed_add = (uint32_t)(float)(first_frame + frame_k) * 12345u;
-                        rt::lane_begin_pixel(sc, f, L[i], px, py, st[i], park[i], n_rays, nullptr);
+                        rt::lane_begin_pixel(sc, f, L[i], px, py, st[i], park[i], n_rays, &cnt);
                     }
                 }
                 pool_next += std::min<uint32_t>(n_need, 64 - pool_next);
@@ -243,8 +246,8 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
                 for (int i = 0; i < 64; i++)
                     if (L[i].mode == rt::kLaneTraverse && rt::link_is_inner(L[i].cur)) {
                         if (L[i].cur >= n_nodes4) { bad_links++; L[i].cur = rt::kNoRoot; L[i].mode = rt::kLaneShadeClosest; continue; }
-                        if (link_mode == 16) rt::lane_step_node<16>(sc, L[i], st[i], nullptr);
-                        else rt::lane_step_node(sc, L[i], st[i], nullptr);
+                        if (link_mode == 16) rt::lane_step_node<16>(sc, L[i], st[i], &cnt);
+                        else rt::lane_step_node(sc, L[i], st[i], &cnt);
                     }
                 int n_leaf = 0, n_inner = 0;
                 for (auto &l : L) {
@@ -256,14 +259,14 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
                         if (L[i].mode == rt::kLaneTraverse && rt::link_is_leaf(L[i].cur)) {
                             uint32_t code = (uint32_t)~L[i].cur;
                             if ((code >> 3) + (code & 7u) >= bs.n_tris) { bad_links++; L[i].cur = rt::kNoRoot; L[i].mode = rt::kLaneShadeClosest; continue; }
-                            rt::lane_step_triangle(sc, L[i], st[i], nullptr);
+                            rt::lane_step_triangle(sc, L[i], st[i], &cnt);
                         }
                 for (int i = 0; i < 64; i++)
-                    if (L[i].mode == rt::kLaneShadowDone) rt::lane_shadow_done(sc, fp, L[i], st[i], park[i], n_rays, nullptr);
+                    if (L[i].mode == rt::kLaneShadowDone) rt::lane_shadow_done(sc, fp, L[i], st[i], park[i], n_rays, &cnt);
             }
             for (int i = 0; i < 64; i++) {
-                if (L[i].mode == rt::kLaneShadowDone) rt::lane_shadow_done(sc, fp, L[i], st[i], park[i], n_rays, nullptr);
-                if (L[i].mode == rt::kLaneShadeClosest) rt::lane_shade_closest(sc, fp, L[i], st[i], park[i], n_rays, nullptr);
+                if (L[i].mode == rt::kLaneShadowDone) rt::lane_shadow_done(sc, fp, L[i], st[i], park[i], n_rays, &cnt);
+                if (L[i].mode == rt::kLaneShadeClosest) rt::lane_shade_closest(sc, fp, L[i], st[i], park[i], n_rays, &cnt);
             }
             for (int i = 0; i < 64; i++) {
                 if (L[i].mode != rt::kLanePixelDone) continue;
@@ -277,7 +280,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
                 L[i].mode = rt::kLaneNeedUnit;
             }
         }
-        rays += n_rays.calls; traversed += n_rays.traversed;
+        rays += n_rays.calls; traversed += n_rays.traversed; sum_boxes += cnt.boxes; sum_tris += cnt.tris;
         for (auto &x : st) { uint64_t hv = (uint64_t)x.high, cur = high.load(); while (hv > cur && !high.compare_exchange_weak(cur, hv)) {} }
     };
     std::vector<std::thread> th;
@@ -294,7 +297,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
             if (k + 1 == n_frames && frame_f16) std::memcpy(frame_f16 + 4 * p, src, 8);
         }
     }
-    if (counters) { counters[0] += rays; counters[13] += traversed; counters[14] = bs.max_stack4; counters[15] = bs.nodes4.size() / 8; counters[7] = high; }
+    if (counters) { counters[0] += rays; counters[13] += traversed; counters[1] += sum_boxes; counters[2] += sum_tris; counters[14] = bs.max_stack4; counters[15] = bs.nodes4.size() / 8; counters[7] = high; }
     g_link_mode = requested_mode;
     if (bad_links) return -2;      // a link led outside the tables
     return requested_mode < 0 ? link_mode : 0;
