@@ -25,8 +25,28 @@
 
 namespace rt {
 
+#ifndef RT_SCALAR_READS
+#define RT_SCALAR_READS 1
+#endif
 struct f3 { float x, y, z; };
 struct alignas(16) f4 { float x, y, z, w; };
+
+// A 16-byte read whose address is the same in every lane of a wave (a sphere or light record indexed
+// by a loop counter).  Scene tables are never written while a kernel runs, so on the GPU the read goes
+// through the constant address space: the compiler then fetches it once per wave with a scalar load
+// instead of occupying the vector-memory path with 64 copies of one address.
+RT_HD f4 read_uniform(const f4 *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && RT_SCALAR_READS
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    v4f_ v = *(const __attribute__((address_space(4))) v4f_ *)(const void *)p;
+    f4 r;
+    r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+    return r;
+#else
+    return *p;
+#endif
+}
 
 RT_HD f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 RT_HD f3 add(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -485,7 +505,7 @@ RT_HD LightSample sample_light_triangles(const SceneView &sc, f3 hit_point, uint
     float random_power = rand_f(state) * sc.total_power;
     uint32_t sel = sc.n_lights; // trailing zero entry = "var selected_triangle" left at its zero value
     for (uint32_t i = 0; i < sc.n_lights; i++) {
-        if (sc.lights[5 * i + 2].w >= random_power) { sel = i; break; }
+        if (read_uniform(sc.lights + 5 * i + 2).w >= random_power) { sel = i; break; }
     }
     const f4 *L = sc.lights + 5 * (size_t)sel;
     f4 l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3], l4 = L[4];

@@ -150,7 +150,7 @@ RT_HD void lane_pop(Lane &L, Stack &stack)
 RT_HD void lane_test_spheres(const SceneView &sc, Lane &L, TestCounts *cnt)
 {
     for (uint32_t i = 0; i < sc.n_spheres; i++) {
-        f4 s0 = sc.spheres[4 * i];
+        f4 s0 = read_uniform(sc.spheres + 4 * i);
         float tn;
         float t = sphere_t(L.o, L.d, s0, tn);
         if (cnt) cnt->spheres++;
@@ -194,7 +194,7 @@ RT_HD void spheres_closest(const SceneView &sc, f3 o, f3 d, float &best_t, int32
     if (all_nan(d)) return;
     for (uint32_t i = 0; i < sc.n_spheres; i++) {
         float tn;
-        float t = sphere_t(o, d, sc.spheres[4 * i], tn);
+        float t = sphere_t(o, d, read_uniform(sc.spheres + 4 * i), tn);
         if (cnt) cnt->spheres++;
         if (t > 0.0f && (t < best_t || (t == best_t && (int32_t)i < best_id))) { best_t = t; best_id = (int32_t)i; }
     }
