@@ -48,6 +48,22 @@ RT_HD f4 read_uniform(const f4 *p)
 #endif
 }
 
+// A 16-byte read that must stay one load instruction: read as four separate floats, a record whose
+// fourth component is used later than the first three is fetched as 12 + 4 bytes, and every vector
+// load instruction occupies the memory path for at least 16 clocks.
+RT_HD f4 read_whole(const f4 *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    v4f_ v = *(const v4f_ *)(const void *)p;
+    f4 r;
+    r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+    return r;
+#else
+    return *p;
+#endif
+}
+
 RT_HD f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 RT_HD f3 add(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 RT_HD f3 sub(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
@@ -508,7 +524,7 @@ RT_HD LightSample sample_light_triangles(const SceneView &sc, f3 hit_point, uint
         if (read_uniform(sc.lights + 5 * i + 2).w >= random_power) { sel = i; break; }
     }
     const f4 *L = sc.lights + 5 * (size_t)sel;
-    f4 l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3], l4 = L[4];
+    f4 l0 = read_whole(L + 0), l1 = read_whole(L + 1), l2 = L[2], l3 = L[3], l4 = L[4];
 
     // common.wgsl:214-225
     float r1 = rand_f(state);
