@@ -474,7 +474,8 @@ void build_scene(const void *spheres, uint32_t n_spheres, const void *triangles,
         n[6] = mk4(u2f(link[0]), u2f(link[1]), u2f(link[2]), u2f(link[3]));
     }
     out.root4 = 0;
-    pack_links16(out);
+    out.links_packed = 0;
+    if (opt.pack_links) pack_links16(out);
 }
 
 namespace {

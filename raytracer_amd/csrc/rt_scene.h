@@ -34,6 +34,7 @@ struct BuildOptions {
     bool greedy_collapse = false; // 4-wide tree by expanding the child of largest area instead of the cost-optimal cut
     // Stack entries of the fastest kernel variant: if only the cost-optimal cut needs more, the greedy one is taken.
     uint32_t prefer_stack = 22;
+    bool pack_links = true;   // write 16-bit child links into the low bytes of the node planes when they fit
     // Largest coordinate magnitude of any ray origin the tree must serve (camera position, scene
     // extent).  The rounding of the box test and of the triangle test's o - v0 grows with it, so
     // boxes are widened in proportion once it exceeds kOriginMagCovered.

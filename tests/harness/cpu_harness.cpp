@@ -4,6 +4,7 @@
 // the shipped library has no CPU rendering path.
 #include <atomic>
 #include <cstdlib>
+#include <climits>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -29,6 +30,49 @@ struct HostStack {
 static int g_sphere_lights = 0;
 // the opt-in sphere-light extension for the following har_render_frame calls
 extern "C" void har_set_sphere_lights(int enable) { g_sphere_lights = enable; }
+
+// Checks the link packing of the 4-wide nodes against an unpacked build of the same scene: every
+// plane of a packed node lies outwards of (or on) the unpacked one by at most 512 ulp, the low bytes
+// of the x and y planes spell the 16-bit code of the link vector's entry, and the link vector itself
+// is unchanged.  Returns the number of violations, or -1 if the scene's links do not fit 16 bits.
+extern "C" int har_check_link_packing(const void *spheres, uint32_t n_spheres, const void *tris, uint32_t n_tris)
+{
+    rt::BuiltScene a, b;
+    rt::BuildOptions opt;
+    rt::build_scene(spheres, n_spheres, tris, n_tris, opt, a);
+    opt.pack_links = false;
+    rt::build_scene(spheres, n_spheres, tris, n_tris, opt, b);
+    if (a.links_packed != 16) return -1;
+    if (a.nodes4.size() != b.nodes4.size()) return 1 << 30;
+    auto ordered = [](float f) { // integer that orders like the float
+        int32_t i;
+        std::memcpy(&i, &f, 4);
+        return i < 0 ? (int64_t)INT32_MIN - i : (int64_t)i;
+    };
+    int bad = 0;
+    for (size_t n = 0; n < a.nodes4.size() / 8; n++) {
+        const float *pa = &a.nodes4[8 * n].x, *pb = &b.nodes4[8 * n].x;
+        for (int k = 0; k < 4; k++) {
+            uint32_t la, lb;
+            std::memcpy(&la, pa + 24 + k, 4);
+            std::memcpy(&lb, pb + 24 + k, 4);
+            if (la != lb) bad++;
+            uint32_t code = (int32_t)lb == rt::kNoRoot ? 0x7fffu : (lb & 0xffffu);
+            for (int plane = 0; plane < 6; plane++) {
+                float va = pa[4 * plane + k], vb = pb[4 * plane + k];
+                int64_t d = ordered(va) - ordered(vb); // > 0: moved up
+                bool lo = plane < 3;
+                if (plane == 2 || plane == 5) { if (d != 0) bad++; continue; } // z planes carry nothing
+                if (lo ? (d > 0 || d < -512) : (d < 0 || d > 512)) bad++;
+                uint32_t bits;
+                std::memcpy(&bits, &va, 4);
+                uint32_t want = (plane % 3 == 0) ? (code & 0xffu) : (code >> 8);
+                if ((bits & 0xffu) != want) bad++;
+            }
+        }
+    }
+    return bad;
+}
 
 // How the lane emulation reads a node's child links: 0 = from the link vector; -1 = as the kernels do
 // for the scene at hand (16-bit links packed into the low bytes of the node planes when the builder

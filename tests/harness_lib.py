@@ -20,6 +20,8 @@ def lib():
                                           C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int]
     L.har_render_frames_lanes.restype = C.c_int
+    L.har_check_link_packing.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    L.har_check_link_packing.restype = C.c_int
     return L
 
 

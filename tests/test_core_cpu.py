@@ -149,6 +149,28 @@ def test_links_packed_into_the_node_planes(scenes, which, expect):
     assert int(har.counters[0]) == int(orc.counters[0])
 
 
+def test_link_packing_only_moves_planes_outwards(scenes):
+    """Property check of the builder's link packing against an unpacked build of the same scene: planes
+    move outwards by at most 512 ulp, the bytes spell the links, the z planes and the link vector are
+    untouched; scenes with coordinates of both signs, zeros and tiny values included."""
+    import ctypes as C
+
+    from raytracer_amd import scene as S
+    from tests.harness_lib import lib
+    from tests.synth import edge_scenes
+
+    L = lib()
+    cases = dict(scenes)
+    cases.update(edge_scenes())
+    checked = 0
+    for name, sc in cases.items():
+        sp, tr = S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles)
+        rc = L.har_check_link_packing(sp.ctypes.data_as(C.c_void_p), len(sp), tr.ctypes.data_as(C.c_void_p), len(tr))
+        assert rc <= 0, "%s: %d violations" % (name, rc)
+        checked += rc == 0
+    assert checked >= 5
+
+
 @pytest.mark.parametrize("brute", [True, False])
 def test_sphere_light_extension_matches_oracle(brute):
     """The opt-in sampling of emissive spheres (the shader's own sample_light_spheres, which it never
