@@ -146,13 +146,17 @@ RT_HD float luminance(f3 c) { return dot(c, mk3(0.2126f, 0.7152f, 0.0722f)); }
 // nodes4     8 x f4 per 4-wide node (persistent kernel): lo.x[4] lo.y[4] lo.z[4]
 //            hi.x[4] hi.y[4] hi.z[4] links[4] pad; same link encoding; unused
 //            slots (2 and 3 only) carry the link kNoRoot.
-// tri_isect  4 x f4 per triangle in leaf order:
-//            (v0.xyz, e01.x) (e01.yz, e02.xy) (e02.z, bits(original index), 0, 0)
-//            (unit normal.xyz, 0) -- a copy of tri_shade's, so that the back-face
-//            test needs no dependent fetch
+// tri_isect  3 x f4 per triangle in leaf order:
+//            (v0.xyz, e01.x) (e01.yz, e02.xy) (e02.z, unit normal.xyz) -- the normal is
+//            tri_shade's, so that the back-face test needs no further fetch
+// tri_orig   original index of the triangle at each leaf position.  The persistent kernel
+//            numbers triangles by leaf position while it traverses (the record has no room
+//            for the index) and asks this table only where original order matters: ties in t
+//            and the primary-hit id it reports.
 // tri_shade  3 x f4 per triangle in original order:
 //            (normal.xyz, smoothness) (color.xyz, specularProbability)
 //            (emissionColor*emissionStrength, 0)
+// tri_shade_leaf  the same records in leaf order
 // tri_raw    the reference's 96-byte records (brute-force mode only)
 // spheres    the reference's 64-byte records = 4 x f4
 // lights     5 x f4 per emissive triangle in original order, plus one trailing
@@ -165,6 +169,8 @@ struct SceneView {
     const f4 *nodes4;
     const f4 *tri_isect;
     const f4 *tri_shade;
+    const f4 *tri_shade_leaf;
+    const uint32_t *tri_orig;
     const f4 *tri_raw;
     const f4 *spheres;
     const f4 *lights;
@@ -179,10 +185,7 @@ struct SceneView {
 };
 
 constexpr int32_t kNoRoot = 0x7fffffff;
-#ifndef RT_TRI_RECORD
-#define RT_TRI_RECORD 4
-#endif
-constexpr int kTriRecord = RT_TRI_RECORD; // f4 per tri_isect record: 3 = without the normal copy, 4 = with it
+constexpr int kTriRecord = 3; // f4 per tri_isect record
 
 // Per-frame constants derived from the 80-byte uniforms on the host.
 // raytracer_compute.wgsl:290-316 computes these per pixel from the same inputs.
@@ -341,14 +344,14 @@ RT_HD int32_t trace_closest(const SceneView &sc, f3 ro, f3 rd, Stack &stack, flo
                 uint32_t first = code >> 3, count = (code & 7u) + 1u;
                 for (uint32_t k = 0; k < count; k++) {
                     const f4 *tr = sc.tri_isect + kTriRecord * (size_t)(first + k);
-                    f4 a = tr[0], b = tr[1], c = tr[2], nq = kTriRecord == 4 ? tr[3] : sc.tri_shade[3 * (size_t)f2u(tr[2].y)];
+                    f4 a = tr[0], b = tr[1], c = tr[2];
                     float t = triangle_t(ro, rd, xyz(a), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x));
                     if (cnt) cnt->tris++;
                     if (!(t > 0.0f)) continue;
-                    int32_t id = (int32_t)(f2u(c.y) + sc.n_spheres);
+                    int32_t id = (int32_t)(sc.tri_orig[first + k] + sc.n_spheres);
                     if (t < best_t || (t == best_t && id < best_id)) {
                         // common.wgsl:202-207 back-face cull on the stored unit normal
-                        f3 nrm = xyz(nq);
+                        f3 nrm = mk3(c.y, c.z, c.w);
                         if (dot(nrm, rd) > 0.0f) continue;
                         best_t = t;
                         best_id = id;
@@ -398,11 +401,11 @@ RT_HD bool trace_occluded(const SceneView &sc, f3 ro, f3 rd, float limit, Stack 
             uint32_t first = code >> 3, count = (code & 7u) + 1u;
             for (uint32_t k = 0; k < count; k++) {
                 const f4 *tr = sc.tri_isect + kTriRecord * (size_t)(first + k);
-                f4 a = tr[0], b = tr[1], c = tr[2], nq = kTriRecord == 4 ? tr[3] : sc.tri_shade[3 * (size_t)f2u(tr[2].y)];
+                f4 a = tr[0], b = tr[1], c = tr[2];
                 float t = triangle_t(ro, rd, xyz(a), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x));
                 if (cnt) cnt->tris++;
                 if (!(t > 0.0f) || t > limit) continue;
-                f3 nrm = xyz(nq);
+                f3 nrm = mk3(c.y, c.z, c.w);
                 if (dot(nrm, rd) > 0.0f) continue;
                 return true;
             }
@@ -458,6 +461,9 @@ RT_HD int32_t brute_closest(const SceneView &sc, f3 ro, f3 rd, float &out_t)
 }
 
 // HitInfo of a traced id (the fields ray_sphere_intersect / ray_triangle_intersect return).
+// LEAF_IDS: triangle ids count leaf positions (the persistent kernel's numbering) instead of
+// original indices.
+template <bool LEAF_IDS = false>
 RT_HD Hit fetch_hit(const SceneView &sc, f3 ro, f3 rd, int32_t id, float t)
 {
     Hit h;
@@ -489,7 +495,7 @@ RT_HD Hit fetch_hit(const SceneView &sc, f3 ro, f3 rd, int32_t id, float t)
         h.emission = scale(mk3(0.0f, 0.0f, 0.0f), 0.0f);
         h.specularProbability = 0.0f;
     } else {
-        const f4 *s = sc.tri_shade + 3 * (size_t)((uint32_t)id - sc.n_spheres);
+        const f4 *s = (LEAF_IDS ? sc.tri_shade_leaf : sc.tri_shade) + 3 * (size_t)((uint32_t)id - sc.n_spheres);
         f4 a = s[0], b = s[1], c = s[2];
         h.normal = xyz(a);
         h.smoothness = a.w;

@@ -364,14 +364,14 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
             int px = (int)((tile % tiles_x) * 8u + (slot & 7u));
             int ly = (int)((tile / tiles_x) * 8u + (slot >> 3));
             int py = stripe_global_row(sm, ly);
-            if (FUSED) store_pixel(fp, fb, px, py, color, rt::lane_primary_id(park), bp.sum);
+            if (FUSED) store_pixel(fp, fb, px, py, color, rt::lane_primary_id(sc, park), bp.sum);
             else {
                 size_t lp = (size_t)ly * fp.width + px;
                 uint2 packed;
                 packed.x = (uint32_t)rt::f32_to_f16_bits(color.x) | ((uint32_t)rt::f32_to_f16_bits(color.y) << 16);
                 packed.y = (uint32_t)rt::f32_to_f16_bits(color.z) | (0x3c00u << 16);
                 bp.colors[(size_t)frame_k * ((size_t)local_rows * fp.width) + lp] = packed;
-                if (frame_k + 1u == bp.n_frames) bp.ids[(size_t)py * fp.width + px] = rt::lane_primary_id(park);
+                if (frame_k + 1u == bp.n_frames) bp.ids[(size_t)py * fp.width + px] = rt::lane_primary_id(sc, park);
             }
             L.mode = rt::kLaneNeedUnit;
         }
@@ -633,6 +633,8 @@ struct rt_context {
     // scene
     rt::BuiltScene host_scene;
     rt::SceneView view{};
+    uint32_t *d_tri_orig = nullptr;
+    rt::f4 *d_tri_shade_leaf = nullptr;
     rt::f4 *d_nodes = nullptr, *d_nodes4 = nullptr, *d_tri_isect = nullptr, *d_tri_shade = nullptr, *d_tri_raw = nullptr, *d_spheres = nullptr,
            *d_lights = nullptr;
     bool has_scene = false;
@@ -687,8 +689,10 @@ struct rt_context {
 
     void free_scene()
     {
-        for (rt::f4 *p : {d_nodes, d_nodes4, d_tri_isect, d_tri_shade, d_tri_raw, d_spheres, d_lights}) (void)hipFree(p);
-        d_nodes = d_nodes4 = d_tri_isect = d_tri_shade = d_tri_raw = d_spheres = d_lights = nullptr;
+        for (rt::f4 *p : {d_nodes, d_nodes4, d_tri_isect, d_tri_shade, d_tri_shade_leaf, d_tri_raw, d_spheres, d_lights}) (void)hipFree(p);
+        (void)hipFree(d_tri_orig);
+        d_tri_orig = nullptr;
+        d_nodes = d_nodes4 = d_tri_isect = d_tri_shade = d_tri_shade_leaf = d_tri_raw = d_spheres = d_lights = nullptr;
         has_scene = false;
     }
 };
@@ -1082,15 +1086,16 @@ static int upload_scene(rt_context *c, const void *spheres, uint32_t n_spheres, 
     const rt::BuiltScene &hs = c->host_scene;
     int rc;
     if ((rc = upload(hs.nodes, &c->d_nodes, c->stream)) || (rc = upload(hs.nodes4, &c->d_nodes4, c->stream)) || (rc = upload(hs.tri_isect, &c->d_tri_isect, c->stream)) ||
-        (rc = upload(hs.tri_shade, &c->d_tri_shade, c->stream)) || (rc = upload(hs.tri_raw, &c->d_tri_raw, c->stream)) ||
+        (rc = upload(hs.tri_shade, &c->d_tri_shade, c->stream)) || (rc = upload(hs.tri_shade_leaf, &c->d_tri_shade_leaf, c->stream)) ||
+        (rc = upload(hs.tri_orig, &c->d_tri_orig, c->stream)) || (rc = upload(hs.tri_raw, &c->d_tri_raw, c->stream)) ||
         (rc = upload(hs.spheres, &c->d_spheres, c->stream)) || (rc = upload(hs.lights, &c->d_lights, c->stream))) {
         c->free_scene();
         return rc;
     }
     RT_HIP_CHECK(hipStreamSynchronize(c->stream));
-    c->scene_bytes = (hs.nodes.size() + hs.nodes4.size() + hs.tri_isect.size() + hs.tri_shade.size() + hs.spheres.size() + hs.lights.size()) * sizeof(rt::f4);
+    c->scene_bytes = (hs.nodes.size() + hs.nodes4.size() + hs.tri_isect.size() + hs.tri_shade.size() + hs.tri_shade_leaf.size() + hs.tri_orig.size() / 4 + hs.spheres.size() + hs.lights.size()) * sizeof(rt::f4);
     rt::SceneView &v = c->view;
-    v.nodes = c->d_nodes; v.nodes4 = c->d_nodes4; v.root4 = hs.root4; v.tri_isect = c->d_tri_isect; v.tri_shade = c->d_tri_shade; v.tri_raw = c->d_tri_raw;
+    v.nodes = c->d_nodes; v.nodes4 = c->d_nodes4; v.root4 = hs.root4; v.tri_isect = c->d_tri_isect; v.tri_shade = c->d_tri_shade; v.tri_shade_leaf = c->d_tri_shade_leaf; v.tri_orig = c->d_tri_orig; v.tri_raw = c->d_tri_raw;
     v.spheres = c->d_spheres; v.lights = c->d_lights;
     v.n_spheres = hs.n_spheres; v.n_tris = hs.n_tris; v.n_lights = hs.n_lights; v.n_lights_pass1 = hs.n_lights_pass1;
     v.total_power = hs.total_power; v.root = hs.root;

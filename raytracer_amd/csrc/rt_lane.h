@@ -115,10 +115,12 @@ RT_HD bool lane_flag(const Lane &L, uint32_t bit) { return (L.bits & bit) != 0u;
 RT_HD void lane_set_flag(Lane &L, uint32_t bit, bool on) { L.bits = on ? (L.bits | bit) : (L.bits & ~bit); }
 // primary-hit id of the pixel (-1 on a miss), valid once the camera ray has been shaded
 template <class Park>
-RT_HD int32_t lane_primary_id(const Park &park)
+RT_HD int32_t lane_primary_id(const SceneView &sc, const Park &park)
 {
     int32_t id = (int32_t)f2u(park.get(kParkPrimId));
-    return id == kNoHit ? -1 : id;
+    if (id == kNoHit) return -1;
+    if ((uint32_t)id < sc.n_spheres) return id;
+    return (int32_t)(sc.tri_orig[(uint32_t)id - sc.n_spheres] + sc.n_spheres); // reported by original index
 }
 
 RT_HD bool link_is_inner(int32_t cur) { return cur >= 0 && cur != kNoRoot; }
@@ -336,6 +338,17 @@ RT_HD void lane_step_node(const SceneView &sc, Lane &L, Stack &stack, TestCounts
     else lane_step_inner(sc, L, stack, cnt);
 }
 
+// The reference's scan keeps the first of several hits at the same t, i.e. the one with the lowest
+// id in its order: spheres, then triangles by original index (raytracer_compute.wgsl:19-36).  id is
+// a triangle by leaf position; best is the lane's best id so far (kNoHit, a sphere, or a triangle by
+// leaf position).  Only reached on an exact tie in t.
+RT_HD bool leaf_id_precedes(const SceneView &sc, int32_t id, int32_t best)
+{
+    if (best == kNoHit) return true;
+    if ((uint32_t)best < sc.n_spheres) return false;
+    return sc.tri_orig[(uint32_t)id - sc.n_spheres] < sc.tri_orig[(uint32_t)best - sc.n_spheres];
+}
+
 // Tests the first triangle of the leaf L.cur and shrinks the leaf by it.
 template <class Stack>
 RT_HD void lane_step_triangle(const SceneView &sc, Lane &L, Stack &stack, TestCounts *cnt)
@@ -343,7 +356,7 @@ RT_HD void lane_step_triangle(const SceneView &sc, Lane &L, Stack &stack, TestCo
     uint32_t code = (uint32_t)~L.cur;
     uint32_t first = code >> 3, left = code & 7u; // triangles after this one
     const f4 *tr = sc.tri_isect + kTriRecord * (size_t)first;
-    f4 a = tr[0], b = tr[1], c = tr[2];
+    f4 a = read_whole(tr + 0), b = read_whole(tr + 1), c = read_whole(tr + 2); // three 16-byte loads, not 12 + 16 + 16 + 4
     float touched = 0.0f;
     if constexpr (stack_touches_top<Stack>::value) {
         // what the lane visits after this leaf is known already: start bringing it into the caches
@@ -353,12 +366,11 @@ RT_HD void lane_step_triangle(const SceneView &sc, Lane &L, Stack &stack, TestCo
     if (cnt) cnt->tris++;
     bool stop = false;
     if (t > 0.0f) {
-        uint32_t orig = f2u(c.y);
-        int32_t id = (int32_t)(orig + sc.n_spheres);
+        int32_t id = (int32_t)(first + sc.n_spheres); // by leaf position, see SceneView::tri_orig
         bool anyhit = lane_flag(L, kBitAnyhit);
-        bool candidate = anyhit ? !(t > L.tmax) : (t < L.tmax || (t == L.tmax && id < L.best_id));
+        bool candidate = anyhit ? !(t > L.tmax) : (t < L.tmax || (t == L.tmax && leaf_id_precedes(sc, id, L.best_id)));
         if (candidate) {
-            f3 nrm = xyz(kTriRecord == 4 ? tr[3] : sc.tri_shade[3 * (size_t)orig]); // common.wgsl:202-207
+            f3 nrm = mk3(c.y, c.z, c.w); // common.wgsl:202-207
             if (!(dot(nrm, L.d) > 0.0f)) {
                 L.best_id = id;
                 if (anyhit) stop = true;
@@ -465,7 +477,7 @@ RT_HD void lane_shade_closest(const SceneView &sc, const FrameParams &fp, Lane &
         end_path = true;
     } else {
         if (cnt) cnt->bounces++;
-        Hit hit = fetch_hit(sc, L.o, L.d, id, t);
+        Hit hit = fetch_hit<true>(sc, L.o, L.d, id, t);
         f3 hit_point = add(L.o, scale(L.d, hit.t));
         LightSample ts = sample_light_triangles(sc, hit_point, L.rng);
         bool shadow = false;

@@ -302,14 +302,18 @@ void build_scene(const void *spheres, uint32_t n_spheres, const void *triangles,
 
     // Leaf-ordered intersection records.
     out.tri_isect.resize((size_t)n_tris * kTriRecord);
+    out.tri_orig.resize(n_tris);
+    out.tri_shade_leaf.resize((size_t)n_tris * 3);
     for (uint32_t k = 0; k < n_tris; k++) {
         const float *r = T + (size_t)prims[k].index * 24;
         f3 v0 = ld3(r), v1 = ld3(r + 4), v2 = ld3(r + 8);
         f3 e01 = sub(v1, v0), e02 = sub(v2, v0); // common.wgsl:172-173
         out.tri_isect[kTriRecord * (size_t)k + 0] = mk4(v0, e01.x);
         out.tri_isect[kTriRecord * (size_t)k + 1] = mk4(e01.y, e01.z, e02.x, e02.y);
-        out.tri_isect[kTriRecord * (size_t)k + 2] = mk4(e02.z, u2f(prims[k].index), 0.0f, 0.0f);
-        if (kTriRecord == 4) out.tri_isect[4 * (size_t)k + 3] = out.tri_shade[3 * (size_t)prims[k].index];
+        const f4 *sh = &out.tri_shade[3 * (size_t)prims[k].index];
+        out.tri_isect[kTriRecord * (size_t)k + 2] = mk4(e02.z, sh[0].x, sh[0].y, sh[0].z);
+        out.tri_orig[k] = prims[k].index;
+        for (int j = 0; j < 3; j++) out.tri_shade_leaf[3 * (size_t)k + j] = sh[j];
     }
 
     // Flatten: inner build nodes get consecutive indices in depth-first order.

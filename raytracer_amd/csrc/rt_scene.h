@@ -12,7 +12,8 @@
 namespace rt {
 
 struct BuiltScene {
-    std::vector<f4> nodes, nodes4, tri_isect, tri_shade, tri_raw, spheres, lights;
+    std::vector<f4> nodes, nodes4, tri_isect, tri_shade, tri_shade_leaf, tri_raw, spheres, lights;
+    std::vector<uint32_t> tri_orig; // original index of the triangle at each leaf position
     uint32_t n_spheres = 0, n_tris = 0, n_lights = 0, n_lights_pass1 = 0;
     float total_power = 0.0f;
     int32_t root = kNoRoot, root4 = kNoRoot;

@@ -93,7 +93,7 @@ extern "C" int har_render_frame(const void *uniforms80, const void *spheres, uin
     if (!rt::make_frame_params(uniforms80, max_bounces, fp, err)) return -1;
     fp.sphere_lights = g_sphere_lights ? 1u : 0u;
     rt::SceneView sc{};
-    sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data();
+    sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data(); sc.tri_shade_leaf = bs.tri_shade_leaf.data(); sc.tri_orig = bs.tri_orig.data();
     sc.tri_raw = bs.tri_raw.data(); sc.spheres = bs.spheres.data(); sc.lights = bs.lights.data();
     sc.n_spheres = bs.n_spheres; sc.n_tris = bs.n_tris; sc.n_lights = bs.n_lights;
     sc.n_lights_pass1 = bs.n_lights_pass1; sc.total_power = bs.total_power; sc.root = bs.root;
@@ -153,7 +153,7 @@ extern "C" int har_debug_pixel(const void *uniforms80, const void *spheres, uint
     std::string err;
     if (!rt::make_frame_params(uniforms80, max_bounces, fp, err)) return -1;
     rt::SceneView sc{};
-    sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data();
+    sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data(); sc.tri_shade_leaf = bs.tri_shade_leaf.data(); sc.tri_orig = bs.tri_orig.data();
     sc.tri_raw = bs.tri_raw.data(); sc.spheres = bs.spheres.data(); sc.lights = bs.lights.data();
     sc.n_spheres = bs.n_spheres; sc.n_tris = bs.n_tris; sc.n_lights = bs.n_lights;
     sc.n_lights_pass1 = bs.n_lights_pass1; sc.total_power = bs.total_power; sc.root = bs.root;
@@ -226,7 +226,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
     std::string err;
     if (!rt::make_frame_params(uni, max_bounces, fp, err)) return -1;
     rt::SceneView sc{};
-    sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data();
+    sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data(); sc.tri_shade_leaf = bs.tri_shade_leaf.data(); sc.tri_orig = bs.tri_orig.data();
     sc.tri_raw = bs.tri_raw.data(); sc.spheres = bs.spheres.data(); sc.lights = bs.lights.data();
     sc.n_spheres = bs.n_spheres; sc.n_tris = bs.n_tris; sc.n_lights = bs.n_lights;
     sc.n_lights_pass1 = bs.n_lights_pass1; sc.total_power = bs.total_power; sc.root = bs.root;
@@ -320,7 +320,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
                 uint16_t *dst = &batch[((size_t)frame_k * W * H + p) * 4];
                 dst[0] = rt::f32_to_f16_bits(c.x); dst[1] = rt::f32_to_f16_bits(c.y);
                 dst[2] = rt::f32_to_f16_bits(c.z); dst[3] = 0x3c00;
-                if (frame_k + 1 == n_frames && ids) ids[p] = rt::lane_primary_id(park[i]);
+                if (frame_k + 1 == n_frames && ids) ids[p] = rt::lane_primary_id(sc, park[i]);
                 L[i].mode = rt::kLaneNeedUnit;
             }
         }
