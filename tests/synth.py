@@ -79,6 +79,14 @@ def edge_scenes() -> dict:
     # two coincident spheres: the lower index must be reported
     many.append(copy.deepcopy(many[3]))
     out["many_spheres"] = S.Scene(camera=boxes.camera, spheres=many, triangles=boxes.triangles)
+    # every triangle of the boxes scene three times, in a seeded shuffle: every hit is an exact tie in t
+    # between copies whose original order and order in the acceleration structure differ; the lowest
+    # original index must be reported, as by the reference's scan
+    import random
+    rng = random.Random(20240611)
+    tripled = [copy.deepcopy(t) for t in boxes.triangles for _ in range(3)]
+    rng.shuffle(tripled)
+    out["shuffled_duplicates"] = S.Scene(camera=boxes.camera, spheres=boxes.spheres, triangles=tripled)
     return out
 
 

@@ -72,7 +72,7 @@ def test_lane_state_machine_matches_oracle(scenes, name, width, height, frames, 
 
 
 EDGE_CASES = ["empty", "spheres_only", "no_lights", "rotated_camera", "camera_down", "emissive_and_mirror_spheres",
-              "duplicates_and_degenerates", "many_spheres"]
+              "duplicates_and_degenerates", "many_spheres", "shuffled_duplicates"]
 
 
 @pytest.mark.parametrize("name", EDGE_CASES)

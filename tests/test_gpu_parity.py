@@ -228,7 +228,7 @@ def test_frame_split_sums_match_the_recurrence(scenes):
 
 
 @pytest.mark.parametrize("name", ["empty", "spheres_only", "no_lights", "rotated_camera", "camera_down",
-                                  "emissive_and_mirror_spheres", "duplicates_and_degenerates", "many_spheres"])
+                                  "emissive_and_mirror_spheres", "duplicates_and_degenerates", "many_spheres", "shuffled_duplicates"])
 def test_edge_scenes_bit_exact(name):
     """Empty inputs, no lights, rotated cameras, emissive / mirror spheres, coincident and degenerate
     triangles, a long sphere list: single frames (fused epilogue) and a batch, all modes for the first."""
