@@ -68,6 +68,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = every rank keeps the N = 1 amount of work (K*N frames in total); strong = the job is "
+                         "fixed (K frames in total) and each rank gets 1/N of it")
     ap.add_argument("--split", choices=["rows", "frames"], default=None,
                     help="N > 1: deal image rows (exact) or frames (sums + all-reduce) to the ranks; default by config")
     return ap.parse_args()
@@ -191,7 +194,8 @@ def main():
 
     ctx, scene_seconds = new_context()
 
-    frames_per_step = world  # weak scaling: every rank keeps the N = 1 amount of work
+    # weak scaling: every rank keeps the N = 1 amount of work; strong scaling: K frames whatever N
+    frames_per_step = world if args.scaling == "weak" else 1
     K, W = args.steps, args.warmup
 
     def barrier():
@@ -327,7 +331,7 @@ def main():
             rec = json.load(open(pmc)).get(args.config)
             if rec:
                 traffic = rec["hbm_bytes_per_frame"] * frames_in_launch
-                traffic_note = rec.get("source", "")
+                traffic_note = "recorded, not measured by this run: profiles/pmc_traffic.json, bytes per frame x frames per launch; " + rec.get("source", "")
         except Exception:
             traffic = None
     valu = None
@@ -340,11 +344,15 @@ def main():
             if k:
                 valu = {"valu_insts_per_simd_cycle": k["valu_insts_per_simd_cycle"], "ceiling_plain_fma": rec["ceiling_plain_fma"],
                         "frac_of_ceiling": k["valu_insts_per_simd_cycle"] / rec["ceiling_plain_fma"],
-                        "lanes_active_per_valu_inst": k["lanes_active_per_valu_inst"], "source": rec.get("source", "")}
+                        "lanes_active_per_valu_inst": k["lanes_active_per_valu_inst"], "source": rec.get("source", ""),
+                        "recorded_from": "profiles/valu_calibration.json (rocprofv3 --pmc passes of an earlier run of this "
+                                         "configuration; not measured by this run)"}
                 if "l1_access_ceiling_per_cu_cycle" in rec and "l1_accesses_per_cu_cycle" in k:
                     l1 = {"accesses_per_cu_cycle": k["l1_accesses_per_cu_cycle"], "ceiling": rec["l1_access_ceiling_per_cu_cycle"],
                           "frac_of_ceiling": k["l1_accesses_per_cu_cycle"] / rec["l1_access_ceiling_per_cu_cycle"],
-                          "accesses_per_ray": k.get("l1_accesses_per_ray"), "source": rec.get("l1_access_ceiling_source", "")}
+                          "accesses_per_ray": k.get("l1_accesses_per_ray"), "source": rec.get("l1_access_ceiling_source", ""),
+                          "recorded_from": "profiles/valu_calibration.json (rocprofv3 --pmc passes of an earlier run of this "
+                                           "configuration; not measured by this run)"}
         except Exception:
             valu = None
 
@@ -357,7 +365,7 @@ def main():
         "warmup": W,
         "ms_per_step": dt * 1e3 / max(K, 1),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": data_note,
@@ -388,6 +396,9 @@ def main():
             "traffic": traffic,
             "algorithmic_bytes": algorithmic_bytes,
             "traffic_note": traffic_note,
+            "measured_by_this_run": ["achieved", "frac", "kernel_ms_per_launch", "rays_per_launch", "flops_per_ray", "per_ray",
+                                     "lane_utilisation", "brute_force_equivalent"],
+            "recorded_from_profiles": ["traffic", "valu_issue", "l1_access"],
             "kernel": "render_persistent_kernel (path trace of up to %d frames per launch; the ordered accumulate kernel "
                       "that follows it is included in the timing and is < 0.1%% of it)" % batch,
             "launches": launches,

@@ -92,8 +92,10 @@ int rt_create(int device, int width, int height,
               int stripe_rows, int stripe_index, int stripe_count,
               rt_context **out);
 
-/* Frees all device memory of the context.  The reference never destroys its
- * renderer; a scene switch builds a new one (src/main.ts:31-35). */
+/* Frees all device memory of the context; frames rt_render_frame still holds
+ * back are dropped, not rendered (call rt_sync first to have them).  The
+ * reference never destroys its renderer; a scene switch builds a new one
+ * (src/main.ts:31-35). */
 void rt_destroy(rt_context *ctx);
 
 /*
@@ -163,8 +165,10 @@ int rt_set_tuning(rt_context *ctx, int key, int value);
  * older launch, so such a loop cannot run ahead without bound).  Frames are
  * accumulated in frame order, and every other entry point first launches what
  * is held back: the effects of the calls are those of launching each frame in
- * its own call.  An error in a held-back launch is reported by the call that
- * launches it.
+ * its own call, except for two things a caller can observe: an error in a
+ * held-back launch (a device error; arguments are checked before a frame is
+ * queued) is reported by the call that launches it, and rt_last_render_ms
+ * covers the whole batch.  rt_destroy discards frames still held back.
  */
 int rt_render_frame(rt_context *ctx);
 
@@ -187,9 +191,9 @@ int rt_render_frames(rt_context *ctx, uint32_t first_frame_index, uint32_t n_fra
  * Limits, reported as RT_ERR_UNSUPPORTED with a message:
  *   - the context may own at most 8,388,608 pixels (64 MiB / 8 B; a 3840x2160 image fits);
  *     frames per launch are limited to what fits, so very large images trace one frame per launch;
- *   - scenes whose traversal needs the stack overflow area in global memory (4-wide trees deeper
- *     than 16 entries over more than 4096 triangles) must have been rendered once with
- *     rt_render_frames, which allocates that area;
+ *   - scenes whose traversal needs the stack overflow area in global memory (4-wide trees that need
+ *     more than 12 stack entries over more than 4096 triangles) get that area from rt_set_scene,
+ *     sized for the launch shape in force then; raising RT_TUNE_BLOCKS_PER_CU afterwards is refused;
  *   - a camera that moved so far out that the acceleration structure must be rebuilt is refused.
  * All contexts on one GPU share that GPU's array, on their own streams: calls on different
  * contexts of one GPU must not overlap in time (finish one with rt_sync before starting another),
@@ -202,10 +206,16 @@ int rt_render_frames_noalloc(rt_context *ctx, uint32_t first_frame_index, uint32
 int rt_sync(rt_context *ctx);
 
 /* Milliseconds between the start and the end on the GPU of the most recent
- * rt_render_frame / rt_render_frames call (HIP events); waits for it.  Single
+ * launch group (HIP events); waits for it.  For rt_render_frames that is the
+ * whole call.  For rt_render_frame it is the frame's own launch, or, when the
+ * frame was held back and launched with others as one batch, that whole batch
+ * (up to RT_TUNE_COALESCE_FRAMES frames): rt_last_render_frames says how many
+ * frames the figure covers, so ms / frames is the per-frame time.  Single
  * frames submitted back to back overlap on the GPU, so their times do not add
  * up to the elapsed time. */
 int rt_last_render_ms(rt_context *ctx, float *ms);
+/* Frames covered by the figure rt_last_render_ms returns (launches what is held back first). */
+int rt_last_render_frames(rt_context *ctx, uint32_t *frames);
 
 /*
  * Read back the accumulator (the three r32float planes of
@@ -214,6 +224,13 @@ int rt_last_render_ms(rt_context *ctx, float *ms);
  * own read as 0.
  */
 int rt_read_accum(rt_context *ctx, float *rgb);
+
+/* Inverse of rt_read_accum: replace the accumulator planes by width*height
+ * interleaved RGB float32 from host memory, and wait for the copy.  No
+ * counterpart in the reference.  For hosts without device buffers of their own
+ * (the Node addon) that combine frame-split sums (rt_render_frame_sums) of
+ * several GPUs in host memory before rt_finish_frame_sums. */
+int rt_write_accum(rt_context *ctx, const float *rgb);
 
 /* Read back the last frame's rgba16float intermediate texture
  * (src/webgpu-renderer.ts:108-112): width*height*4 half-float bit patterns. */

@@ -43,7 +43,9 @@ SYMBOLS = {
     "rt_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_sync": (C.c_int, [C.c_void_p]),
     "rt_last_render_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "rt_last_render_frames": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "rt_read_accum": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_write_accum": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_read_frame_f16": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_read_primary_ids": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_read_counters": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -181,10 +183,20 @@ class Context:
         _check(self.lib.rt_last_render_ms(self.handle, C.byref(ms)))
         return ms.value
 
+    def last_render_frames(self) -> int:
+        v = C.c_uint32()
+        _check(self.lib.rt_last_render_frames(self.handle, C.byref(v)))
+        return v.value
+
     def read_accum(self) -> np.ndarray:
         out = np.empty((self.height, self.width, 3), dtype=np.float32)
         _check(self.lib.rt_read_accum(self.handle, _ptr(out)))
         return out
+
+    def write_accum(self, rgb: np.ndarray):
+        rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+        assert rgb.size == self.width * self.height * 3
+        _check(self.lib.rt_write_accum(self.handle, _ptr(rgb)))
 
     def read_frame_f16(self) -> np.ndarray:
         out = np.empty((self.height, self.width, 4), dtype=np.uint16)

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <type_traits>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -42,17 +43,26 @@ int fail(int code, const std::string &msg)
 // code the array's name is only a handle: its device address comes from hipGetSymbolAddress, once per
 // device (scratch_of), and only that pointer is ever passed to kernels and memsets.
 // ---------------------------------------------------------------------------
-constexpr size_t kScratchHeader = 512;
+constexpr uint32_t kQueues = 8;       // work queues of a launch of the persistent kernel: one per XCD
+constexpr uint32_t kQueueStride = 16; // their counters are 64 bytes apart
+constexpr uint32_t kLaunchCounters = kQueues * kQueueStride; // counters one launch uses (128 dwords)
+constexpr size_t kScratchHeader = (kLaunchCounters * sizeof(unsigned int) + 255) / 256 * 256;
+static_assert(kScratchHeader >= kLaunchCounters * sizeof(unsigned int) && kScratchHeader % 256 == 0,
+              "the counters of a launch must fit in front of the colours");
 constexpr size_t kScratchColorBytes = (size_t)64 << 20; // 8,388,608 pixel-frames: one 3840x2160 frame, four 1920x1080 frames
 static __device__ __align__(256) unsigned char scratch[kScratchHeader + kScratchColorBytes];
 
 constexpr int kMaxDevices = 64;
 void *g_scratch_ptr[kMaxDevices] = {nullptr};
+std::mutex g_scratch_mutex; // contexts may be created and used from one host thread per device
 
-// Device address of `scratch` on `device`, which must be the current device.
+// Device address of `scratch` on `device`, which must be the current device.  Resolved on the first
+// rt_render_frames_noalloc call on that device; the other entry points never need it.
 int scratch_of(int device, void **out)
 {
-    if (device < 0 || device >= kMaxDevices) return fail(RT_ERR_UNSUPPORTED, "device index beyond the library's table");
+    if (device < 0 || device >= kMaxDevices)
+        return fail(RT_ERR_UNSUPPORTED, "rt_render_frames_noalloc: device index beyond the library's table of 64 devices");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[device]) {
         void *p = nullptr;
         RT_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
@@ -222,8 +232,6 @@ __device__ inline void store_pixel(const rt::FrameParams &fp, const FrameBuffers
 // reference's @workgroup_size(8, 8); four tiles per 256-thread block.
 // ---------------------------------------------------------------------------
 constexpr int kBlock = 256;
-constexpr uint32_t kQueues = 8;       // work queues of a launch of the persistent kernel: one per XCD
-constexpr uint32_t kQueueStride = 16; // their counters are 64 bytes apart
 #ifndef RT_MINW
 #define RT_MINW 5 // waves per SIMD the persistent kernel is compiled for when lane state stays in registers (<= 96 VGPRs)
 #endif
@@ -625,6 +633,7 @@ struct rt_context {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
+    uint32_t timed_frames = 0; // frames between ev_start and ev_stop
     void *scratch = nullptr; // this device's copy of the fixed workspace (rt_render_frames_noalloc)
     bool no_alloc = false;   // set for the duration of an rt_render_frames_noalloc call
 
@@ -681,6 +690,8 @@ struct rt_context {
             if (s == aux[k]) return 1 + k;
         return 0;
     }
+    float *d_row_staging = nullptr; // device block the host-memory row exchange (rt_read_owned_rows / rt_write_rows) goes through
+    size_t row_staging_bytes = 0;
     int tune_max_stack = 64;
     int tune_shade_wait = 12;
     bool debug_view = false;    // opt-in extension: uniforms.debugEnabled draws the triangles' normal markers (brute-force kernel)
@@ -699,7 +710,6 @@ struct rt_context {
 
 namespace {
 
-constexpr uint32_t kLaunchCounters = kQueues * kQueueStride; // counters one launch uses (128 dwords)
 constexpr uint32_t kWorkCounters = 64 * kLaunchCounters;     // ring of launches; far more than can be in flight
 constexpr size_t kBatchBytesCap = (size_t)2 << 30;
 constexpr uint64_t kUnitsPerLaunch = 64ull * 1920 * 1080;
@@ -734,6 +744,8 @@ int launch_tiles(rt_context *c, const rt::FrameParams &fp, bool sum)
     return RT_OK;
 }
 
+int ensure_spill(rt_context *c, int which, hipStream_t stream, uint64_t blocks);
+
 template <class CFG, bool COUNT, bool FUSED>
 int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchParams &bp, unsigned int *counter, hipStream_t stream)
 {
@@ -750,20 +762,10 @@ int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchPar
     if (blocks == 0) return RT_OK;
     if (CFG::SPILL) {
         // one column of kSpillEntries per lane of the grid; launches that share it are serialised by their
-        // streams only within a stream, so every stream (main, two side streams) has its own buffer
-        int which = c->stream_index(stream);
-        size_t need = (size_t)blocks * kBlock * kSpillEntries * sizeof(int32_t);
-        if (c->spill_bytes[which] < need) {
-            if (c->no_alloc)
-                return fail(RT_ERR_UNSUPPORTED, "this scene's traversal needs the stack overflow area in global memory, which "
-                                                "rt_render_frames_noalloc cannot allocate; render once with rt_render_frames first");
-            RT_HIP_CHECK(hipStreamSynchronize(stream));
-            (void)hipFree(c->d_spill[which]);
-            c->d_spill[which] = nullptr;
-            c->spill_bytes[which] = 0;
-            RT_HIP_CHECK(hipMalloc((void **)&c->d_spill[which], need));
-            c->spill_bytes[which] = need;
-        }
+        // streams only within a stream, so every stream (main, side streams) has its own buffer.  The main
+        // stream's is sized when the scene is uploaded (rt_render_frames_noalloc depends on that).
+        int rc = ensure_spill(c, c->stream_index(stream), stream, blocks);
+        if (rc) return rc;
     }
     int32_t *spill = CFG::SPILL ? c->d_spill[c->stream_index(stream)] : nullptr;
     // Starting a pixel (seed, jitter, camera ray) is long code: with few samples per pixel it runs
@@ -792,6 +794,55 @@ using CfgLarge = LaneCfg<RT_LARGE_STACK, RT_LARGE_SLOTS, RT_LARGE_MINW, false, f
 using CfgLargeDeep = LaneCfg<RT_LARGE_STACK, RT_LARGE_SLOTS, RT_LARGE_MINW, false, true>;
 using CfgRegisters = LaneCfg<64, 0, 2, false, false>; // 64 KB of LDS per block: two blocks per CU
 
+// Scenes whose links fit 16 bits: node indices below 32768 and leaf codes (first << 3 | count - 1) below 32768.
+bool scene_is_small(const rt_context *c)
+{
+    const rt::BuiltScene &hs = c->host_scene;
+    return hs.n_tris <= 4096 && hs.nodes.size() / 4 < 32768 && hs.nodes4.size() / 8 < 32768 && persistent_stack_need(c) <= 32 &&
+           (hs.links_packed == 16 || !RT_PACKED_LINKS);
+}
+
+// Whether the persistent kernel renders the current scene with the instantiation that keeps the deep end of
+// its traversal stack in global memory.
+bool scene_spills(const rt_context *c)
+{
+    return rt::kWideBvh && c->tune_lds_state != 0 && !scene_is_small(c) && persistent_stack_need(c) > (uint32_t)CfgLarge::STACK &&
+           persistent_stack_need(c) <= kMaxStackEntries;
+}
+
+// Makes the stack overflow area of stream `which` (0 main, 1.. side streams) hold a column per lane of `blocks` blocks.
+int ensure_spill(rt_context *c, int which, hipStream_t stream, uint64_t blocks)
+{
+    size_t need = (size_t)blocks * kBlock * kSpillEntries * sizeof(int32_t);
+    if (c->spill_bytes[which] >= need) return RT_OK;
+    if (c->no_alloc)
+        return fail(RT_ERR_UNSUPPORTED, "rt_render_frames_noalloc: the stack overflow area in global memory is smaller than this launch "
+                                        "needs (RT_TUNE_BLOCKS_PER_CU was raised after rt_set_scene sized it), and it cannot allocate");
+    if (stream) RT_HIP_CHECK(hipStreamSynchronize(stream));
+    (void)hipFree(c->d_spill[which]);
+    c->d_spill[which] = nullptr;
+    c->spill_bytes[which] = 0;
+    RT_HIP_CHECK(hipMalloc((void **)&c->d_spill[which], need));
+    c->spill_bytes[which] = need;
+    return RT_OK;
+}
+
+// The most blocks any launch of the spilling instantiation puts on the device.
+int spill_blocks_max(rt_context *c, uint64_t &blocks)
+{
+    int most = c->tune_blocks_per_cu;
+    if (most <= 0) {
+        int n[4] = {0, 0, 0, 0};
+        RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[0], render_persistent_kernel<CfgLargeDeep, false, false>, kBlock, 0));
+        RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[1], render_persistent_kernel<CfgLargeDeep, false, true>, kBlock, 0));
+        RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[2], render_persistent_kernel<CfgLargeDeep, true, false>, kBlock, 0));
+        RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[3], render_persistent_kernel<CfgLargeDeep, true, true>, kBlock, 0));
+        most = std::max(1, std::max(std::max(n[0], n[1]), std::max(n[2], n[3])));
+    }
+    blocks = (uint64_t)c->n_cus * most;
+    return RT_OK;
+}
+
 template <bool COUNT, bool FUSED>
 int launch_persistent_d(rt_context *c, const rt::FrameParams &fp, const BatchParams &bp, unsigned int *counter, hipStream_t stream)
 {
@@ -799,10 +850,7 @@ int launch_persistent_d(rt_context *c, const rt::FrameParams &fp, const BatchPar
     uint32_t depth = persistent_stack_need(c);
     if (depth > kMaxStackEntries) return fail(RT_ERR_UNSUPPORTED, "acceleration structure too deep for the traversal stack");
     if (c->tune_lds_state == 0 || !rt::kWideBvh) return launch_persistent_t<CfgRegisters, COUNT, FUSED>(c, fp, bp, counter, stream);
-    // 16-bit links: node indices below 32768 and leaf codes (first << 3 | count - 1) below 32768
-    const rt::BuiltScene &hs = c->host_scene;
-    bool small = hs.n_tris <= 4096 && hs.nodes.size() / 4 < 32768 && hs.nodes4.size() / 8 < 32768 && depth <= 32 &&
-                 (hs.links_packed == 16 || !RT_PACKED_LINKS);
+    bool small = scene_is_small(c);
     if (small) {
         if (depth <= (uint32_t)CfgSmall::STACK && c->tune_lds_state >= 2) return launch_persistent_t<CfgSmall, COUNT, FUSED>(c, fp, bp, counter, stream);
         return launch_persistent_t<CfgSmallDeep, COUNT, FUSED>(c, fp, bp, counter, stream);
@@ -816,11 +864,11 @@ int ensure_slots(rt_context *c)
 {
     size_t local_px = (size_t)c->local_rows * c->width, px = (size_t)c->width * c->height;
     for (int k = 0; k < c->tune_overlap && k < rt_context::kMaxSlots; k++) {
-        if (c->aux[k]) continue;
-        RT_HIP_CHECK(hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
-        RT_HIP_CHECK(hipEventCreateWithFlags(&c->trace_done[k], hipEventDisableTiming));
-        RT_HIP_CHECK(hipEventCreateWithFlags(&c->slot_free[k], hipEventDisableTiming));
-        RT_HIP_CHECK(hipMalloc((void **)&c->d_slot[k], std::max<size_t>(local_px, 1) * sizeof(uint2)));
+        if (c->d_slot_ids[k]) continue; // the last resource made: a slot whose creation failed half way is completed here
+        if (!c->aux[k]) RT_HIP_CHECK(hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
+        if (!c->trace_done[k]) RT_HIP_CHECK(hipEventCreateWithFlags(&c->trace_done[k], hipEventDisableTiming));
+        if (!c->slot_free[k]) RT_HIP_CHECK(hipEventCreateWithFlags(&c->slot_free[k], hipEventDisableTiming));
+        if (!c->d_slot[k]) RT_HIP_CHECK(hipMalloc((void **)&c->d_slot[k], std::max<size_t>(local_px, 1) * sizeof(uint2)));
         RT_HIP_CHECK(hipMalloc((void **)&c->d_slot_ids[k], px * sizeof(int32_t)));
     }
     return RT_OK;
@@ -928,6 +976,20 @@ int launch_persistent(rt_context *c, uint32_t first, uint32_t n, uint32_t stride
     return RT_OK;
 }
 
+// The staging block of rt_read_owned_rows / rt_write_rows, kept between calls (both calls end with a
+// stream synchronisation, so it is idle whenever one of them starts).
+int ensure_row_staging(rt_context *c, size_t bytes)
+{
+    if (c->row_staging_bytes >= bytes) return RT_OK;
+    RT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_row_staging);
+    c->d_row_staging = nullptr;
+    c->row_staging_bytes = 0;
+    RT_HIP_CHECK(hipMalloc((void **)&c->d_row_staging, bytes));
+    c->row_staging_bytes = bytes;
+    return RT_OK;
+}
+
 int check_ready(rt_context *c)
 {
     if (!c) return fail(RT_ERR_INVALID, "null context");
@@ -1014,10 +1076,6 @@ int rt_create(int device, int width, int height, int stripe_rows, int stripe_ind
     c->height = height;
     c->sm = StripeMap{stripe_rows, stripe_index, stripe_count};
     c->local_rows = owned_rows_of(height, c->sm);
-    {
-        int rc = scratch_of(device, &c->scratch);
-        if (rc) { rt_destroy(c); return rc; }
-    }
 
     size_t px = (size_t)width * height;
     auto cleanup = [&](int code) { rt_destroy(c); return code; };
@@ -1057,7 +1115,7 @@ void rt_destroy(rt_context *c)
     for (hipEvent_t e : c->flush_done)
         if (e) (void)hipEventDestroy(e);
     for (int32_t *p : c->d_spill) (void)hipFree(p);
-    (void)hipFree(c->d_work); (void)hipFree(c->d_batch);
+    (void)hipFree(c->d_work); (void)hipFree(c->d_batch); (void)hipFree(c->d_row_staging);
     (void)hipFree(c->fb.accum); (void)hipFree(c->fb.frame_f16); (void)hipFree(c->fb.ids); (void)hipFree(c->fb.counters);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
@@ -1101,6 +1159,12 @@ static int upload_scene(rt_context *c, const void *spheres, uint32_t n_spheres, 
     v.total_power = hs.total_power; v.root = hs.root;
     v.debug_view = 0u;
     c->has_scene = true;
+    if (scene_spills(c)) {
+        // the overflow area of the context's own stream is made here, not at the first launch that needs it,
+        // so that rt_render_frames_noalloc never depends on an earlier allocating call
+        uint64_t blocks = 0;
+        if ((rc = spill_blocks_max(c, blocks)) || (rc = ensure_spill(c, 0, nullptr, blocks))) return rc;
+    }
     return RT_OK;
 }
 
@@ -1244,6 +1308,7 @@ static int render_frames_impl(rt_context *c, uint32_t first_frame_index, uint32_
     }
     RT_HIP_CHECK(hipEventRecord(c->ev_stop, c->stream));
     c->timed = true;
+    c->timed_frames = n_frames;
     return RT_OK;
 }
 
@@ -1257,6 +1322,11 @@ int rt_render_frames(rt_context *c, uint32_t first_frame_index, uint32_t n_frame
 int rt_render_frames_noalloc(rt_context *c, uint32_t first_frame_index, uint32_t n_frames)
 {
     if (!c) return fail(RT_ERR_INVALID, "null context");
+    if (!c->scratch) {
+        RT_HIP_CHECK(hipSetDevice(c->device));
+        int rc = scratch_of(c->device, &c->scratch);
+        if (rc) return rc;
+    }
     c->no_alloc = true;
     int rc = flush_pending(c); // frames held back by rt_render_frame go first, through the same workspace
     if (!rc) rc = render_frames_impl(c, first_frame_index, n_frames, 1, false);
@@ -1317,6 +1387,7 @@ int rt_render_frame(rt_context *c)
     int rc = check_ready(c);
     if (rc) return rc;
     uint32_t frame = (uint32_t)c->uniforms[12];
+    if (frame >= (1u << 24)) return fail(RT_ERR_INVALID, "frame index beyond 2^24 is not exact in the f32 uniform");
     bool coalesce = c->tune_coalesce > 1 && c->mode == RT_MODE_BVH && !c->sphere_lights && !debug_view_active(c) && !c->counting &&
                     persistent_stack_need(c) <= (uint32_t)c->tune_max_stack;
     if (!coalesce) {
@@ -1360,6 +1431,15 @@ int rt_last_render_ms(rt_context *c, float *ms)
     return RT_OK;
 }
 
+int rt_last_render_frames(rt_context *c, uint32_t *frames)
+{
+    if (!c || !frames) return fail(RT_ERR_INVALID, "null argument");
+    RT_FLUSH_PENDING(c);
+    if (!c->timed) return fail(RT_ERR_INVALID, "nothing rendered yet");
+    *frames = c->timed_frames;
+    return RT_OK;
+}
+
 int rt_read_accum(rt_context *c, float *rgb)
 {
     if (!c || !rgb) return fail(RT_ERR_INVALID, "null argument");
@@ -1374,6 +1454,23 @@ int rt_read_accum(rt_context *c, float *rgb)
         rgb[3 * i + 1] = planes[px + i];
         rgb[3 * i + 2] = planes[2 * px + i];
     }
+    return RT_OK;
+}
+
+int rt_write_accum(rt_context *c, const float *rgb)
+{
+    if (!c || !rgb) return fail(RT_ERR_INVALID, "null argument");
+    RT_FLUSH_PENDING(c);
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    size_t px = (size_t)c->width * c->height;
+    std::vector<float> planes(px * 3);
+    for (size_t i = 0; i < px; i++) {
+        planes[i] = rgb[3 * i + 0];
+        planes[px + i] = rgb[3 * i + 1];
+        planes[2 * px + i] = rgb[3 * i + 2];
+    }
+    RT_HIP_CHECK(hipMemcpyAsync(c->fb.accum, planes.data(), px * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    RT_HIP_CHECK(hipStreamSynchronize(c->stream)); // `planes` goes out of scope
     return RT_OK;
 }
 
@@ -1527,15 +1624,14 @@ int rt_read_owned_rows(rt_context *c, float *planes)
     RT_HIP_CHECK(hipSetDevice(c->device));
     size_t n = (size_t)c->local_rows * c->width;
     if (n == 0) return RT_OK;
-    float *tmp = nullptr;
-    RT_HIP_CHECK(hipMalloc((void **)&tmp, n * 3 * sizeof(float)));
+    int rc = ensure_row_staging(c, n * 3 * sizeof(float));
+    if (rc) return rc;
+    float *tmp = c->d_row_staging;
     hipLaunchKernelGGL(export_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->fb.accum, tmp, c->width,
                        c->height, c->local_rows, c->sm);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(planes, tmp, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(tmp);
-    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("rt_read_owned_rows: ") + hipGetErrorString(e));
+    RT_HIP_CHECK(hipGetLastError());
+    RT_HIP_CHECK(hipMemcpyAsync(planes, tmp, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP_CHECK(hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 
@@ -1549,15 +1645,13 @@ int rt_write_rows(rt_context *c, const float *planes, int from_index)
     sm.index = from_index;
     size_t n = (size_t)owned_rows_of(c->height, sm) * c->width;
     if (n == 0) return RT_OK;
-    float *tmp = nullptr;
-    RT_HIP_CHECK(hipMalloc((void **)&tmp, n * 3 * sizeof(float)));
-    hipError_t e = hipMemcpyAsync(tmp, planes, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream);
-    int rc = RT_OK;
-    if (e == hipSuccess) rc = rt_import_rows(c, tmp, from_index);
-    if (e == hipSuccess && rc == RT_OK) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(tmp);
-    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("rt_write_rows: ") + hipGetErrorString(e));
-    return rc;
+    int rc = ensure_row_staging(c, n * 3 * sizeof(float));
+    if (rc) return rc;
+    float *tmp = c->d_row_staging;
+    RT_HIP_CHECK(hipMemcpyAsync(tmp, planes, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if ((rc = rt_import_rows(c, tmp, from_index))) return rc;
+    RT_HIP_CHECK(hipStreamSynchronize(c->stream)); // `planes` may be reused by the caller, and the staging block by the next call
+    return RT_OK;
 }
 
 int rt_frames_per_launch(rt_context *c, uint32_t *frames)

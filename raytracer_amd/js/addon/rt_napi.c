@@ -259,6 +259,68 @@ static napi_value js_last_render_ms(napi_env env, napi_callback_info info)
     return out;
 }
 
+static napi_value js_last_render_frames(napi_env env, napi_callback_info info)
+{
+    napi_value a[1], out;
+    if (!get_args(env, info, 1, a)) return NULL;
+    NEED_CTX(ctx, a[0]);
+    uint32_t n = 0;
+    if (rt_last_render_frames(ctx, &n) != RT_OK) return throw_rt(env, "rt_last_render_frames");
+    NAPI_OK(napi_create_uint32(env, n, &out));
+    return out;
+}
+
+/* Frame-split rendering (rt_render_frame_sums and friends); the sums travel between renderers through
+ * readAccum / writeAccum, i.e. host memory. */
+static napi_value js_clear_accum(napi_env env, napi_callback_info info)
+{
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return NULL;
+    NEED_CTX(ctx, a[0]);
+    if (rt_clear_accum(ctx) != RT_OK) return throw_rt(env, "rt_clear_accum");
+    return NULL;
+}
+
+static napi_value js_render_frame_sums(napi_env env, napi_callback_info info)
+{
+    napi_value a[4];
+    if (!get_args(env, info, 4, a)) return NULL;
+    NEED_CTX(ctx, a[0]);
+    uint32_t first, n, stride;
+    if (!get_u32(env, a[1], &first) || !get_u32(env, a[2], &n) || !get_u32(env, a[3], &stride)) return NULL;
+    if (rt_render_frame_sums(ctx, first, n, stride) != RT_OK) return throw_rt(env, "rt_render_frame_sums");
+    return NULL;
+}
+
+static napi_value js_finish_frame_sums(napi_env env, napi_callback_info info)
+{
+    napi_value a[2];
+    if (!get_args(env, info, 2, a)) return NULL;
+    NEED_CTX(ctx, a[0]);
+    uint32_t total;
+    if (!get_u32(env, a[1], &total)) return NULL;
+    if (rt_finish_frame_sums(ctx, total) != RT_OK) return throw_rt(env, "rt_finish_frame_sums");
+    return NULL;
+}
+
+/* (handle, Float32Array of width*height*3 interleaved RGB) */
+static napi_value js_write_accum(napi_env env, napi_callback_info info)
+{
+    napi_value a[2];
+    if (!get_args(env, info, 2, a)) return NULL;
+    NEED_CTX(ctx, a[0]);
+    handle_box *box = get_box(env, a[0]);
+    float *data;
+    size_t n;
+    if (!get_f32_array(env, a[1], &data, &n)) return NULL;
+    if (n != (size_t)box->width * box->height * 3) {
+        napi_throw_range_error(env, NULL, "expected width * height * 3 floats");
+        return NULL;
+    }
+    if (rt_write_accum(ctx, data) != RT_OK) return throw_rt(env, "rt_write_accum");
+    return NULL;
+}
+
 /* Read-backs into a fresh typed array.  The library always writes the context's own width x height
  * elements, so the buffer is sized from the size the handle was created with; the (width, height)
  * the caller passes must agree with it. */
@@ -393,6 +455,8 @@ static napi_value init(napi_env env, napi_value exports)
         {"renderFrame", js_render_frame}, {"renderFrames", js_render_frames}, {"sync", js_sync},
         {"lastRenderMs", js_last_render_ms}, {"readAccum", js_read_accum}, {"readFrameF16", js_read_frame_f16},
         {"readPrimaryIds", js_read_primary_ids}, {"readCounters", js_read_counters},
+        {"lastRenderFrames", js_last_render_frames}, {"clearAccum", js_clear_accum}, {"renderFrameSums", js_render_frame_sums},
+        {"finishFrameSums", js_finish_frame_sums}, {"writeAccum", js_write_accum},
         {"takeTriangleTests", js_take_triangle_tests}, {"ownedRows", js_owned_rows}, {"sceneStats", js_scene_stats},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {

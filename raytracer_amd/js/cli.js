@@ -8,11 +8,12 @@
  *   node cli.js --scene scene.json --width 640 --height 360 --spp 16 --frames 4
  *               [--bounces 6] [--image out.png | --ppm out.ppm] [--preview-every k]
  *               [--apply-model-transforms] [--sphere-lights] [--debug-view] [--dump prefix] [--per-frame]
- *               [--devices 0,1,...]
+ *               [--devices 0,1,...] [--split rows|frames]
  *
  * --debug-view draws every triangle's normal marker (the shader's unused debug helper).
  * --devices renders with one renderer per listed GPU, image rows dealt to them in 8-row stripes
- * (multi-gpu.js), and writes the assembled image / accumulator.
+ * (multi-gpu.js), and writes the assembled image / accumulator; --split frames deals the frames to the
+ * GPUs instead (whole images per GPU, sums added at the end: approximate, see include/rt_hip.h).
  *
  * --preview-every k rewrites the image file after every k frames (progressive preview).
  */
@@ -38,6 +39,7 @@ function parseArgs(argv) {
         else if (k === '--ppm' || k === '--image') a.ppm = v;
         else if (k === '--preview-every') a.previewEvery = parseInt(v, 10);
         else if (k === '--dump') a.dump = v;
+        else if (k === '--split') a.split = v;
         else if (k === '--devices') a.devices = v.split(',').map((x) => parseInt(x, 10));
         else throw new Error('unknown argument ' + k);
     }
@@ -47,8 +49,8 @@ function parseArgs(argv) {
 
 // several GPUs: rows dealt to one renderer per device, assembled on the first
 async function mainSplit(a) {
-    const { renderSplit } = require('./multi-gpu');
-    const r = await renderSplit(a.scene, { width: a.width, height: a.height, spp: a.spp, frames: a.frames, devices: a.devices,
+    const { renderSplit, renderFrameSplit } = require('./multi-gpu');
+    const r = await (a.split === 'frames' ? renderFrameSplit : renderSplit)(a.scene, { width: a.width, height: a.height, spp: a.spp, frames: a.frames, devices: a.devices,
                                             maxBounces: a.bounces });
     if (a.ppm) {
         const pixels = new Uint8Array(a.width * a.height * 4);

@@ -50,6 +50,11 @@ export class HipRenderer {
     readFrameF16(): Uint16Array;
     getCounters(): number[];
     lastRenderMs(): number;
+    lastRenderFrames(): number;
+    clearAccum(): void;
+    renderFrameSums(firstFrameIndex: number, nFrames: number, stride?: number): void;
+    writeAccum(rgb: Float32Array): void;
+    finishFrameSums(nFramesTotal: number): void;
     // multi-GPU row split: rows this renderer owns, their accumulator values (R, G, B planes), and assembly
     ownedRows(): number;
     readOwnedRows(): Float32Array;

@@ -207,12 +207,39 @@ class HipRenderer {
         this.native.writeRows(this.handle, block, fromIndex);
     }
 
+    // Multi-GPU frame split (no counterpart in the reference): renderer r of n renders frames
+    // first + r, first + r + n, ... of the whole image with renderFrameSums(first + r, count, n)
+    // after clearAccum(); the planes then hold plain sums of the frames' colours.  The sums of all
+    // renderers are added on the host (readAccum), written into one of them (writeAccum) and closed
+    // with finishFrameSums(total number of frames).  Approximates the recurrence (include/rt_hip.h).
+    clearAccum() {
+        this.native.clearAccum(this.handle);
+    }
+
+    renderFrameSums(firstFrameIndex, nFrames, stride) {
+        this.native.renderFrameSums(this.handle, firstFrameIndex, nFrames, stride || 1);
+    }
+
+    writeAccum(rgb) {
+        this.native.writeAccum(this.handle, rgb);
+    }
+
+    finishFrameSums(nFramesTotal) {
+        this.native.finishFrameSums(this.handle, nFramesTotal);
+    }
+
     getCounters() {
         return this.native.readCounters(this.handle);
     }
 
+    // GPU time of the most recent launch group and the number of frames it covered: render() calls made
+    // while the GPU is busy are launched together, so the time of "the last frame" is ms / frames
     lastRenderMs() {
         return this.native.lastRenderMs(this.handle);
+    }
+
+    lastRenderFrames() {
+        return this.native.lastRenderFrames(this.handle);
     }
 
     destroy() {

@@ -328,9 +328,9 @@ def test_back_to_back_single_frames(scenes, overlap):
 
 
 def test_card_deck_uses_the_stack_overflow_area():
-    """6,014 triangles stacked so that camera rays leave more than 16 entries on the traversal stack
-    (tests/test_core_cpu.py checks that depth on the emulated lanes): entries beyond the 16 in LDS go
-    to global memory."""
+    """6,014 triangles stacked so that camera rays leave 18 entries on the traversal stack
+    (tests/test_core_cpu.py checks that depth on the emulated lanes): entries beyond the 12 that the
+    large-scene kernel keeps in LDS go to global memory."""
     from tests.synth import card_deck_scene
 
     scene = card_deck_scene(3000)

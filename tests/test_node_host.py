@@ -108,7 +108,8 @@ def test_addon_exports_the_abi():
     script = "const a = require('%s/rt_hip_napi.node'); console.log(JSON.stringify(Object.keys(a).sort()))" % JS
     names = json.loads(node(script))
     for n in ["setSphereLights", "create", "destroy", "setScene", "setUniforms", "renderFrame", "renderFrames", "readAccum",
-              "readPrimaryIds", "readFrameF16", "takeTriangleTests", "readCounters", "deviceCount", "sync"]:
+              "readPrimaryIds", "readFrameF16", "takeTriangleTests", "readCounters", "deviceCount", "sync",
+              "clearAccum", "renderFrameSums", "finishFrameSums", "writeAccum", "lastRenderFrames"]:
         assert n in names
 
 
@@ -201,6 +202,43 @@ renderSplit('%(scene)s', { width: %(w)d, height: %(h)d, spp: %(spp)d, frames: %(
     orc.render_frames(frames)
     acc = np.fromfile(tmp_path / "split.f32", np.float32).reshape(height, width, 3)
     assert np.array_equal(acc, orc.accum_rgb())
+    assert info["rays"] == int(orc.counters[0])
+
+
+@pytest.mark.gpu
+def test_js_frame_split_matches_the_recurrence_up_to_rounding(scenes, tmp_path):
+    """raytracer_amd/js/multi-gpu.js renderFrameSplit with two renderers on the one GPU of the box: frames
+    dealt round-robin, sums added on the host, closed with finishFrameSums.  Against the oracle's
+    sequential accumulator: rounding-level agreement on pixels the recurrence never clamps, the exact
+    closed form everywhere, and the same ray count."""
+    width, height, spp, frames = 96, 54, 2, 5
+    script = """
+const fs = require('fs');
+const { renderFrameSplit } = require('%(js)s/multi-gpu');
+renderFrameSplit('%(scene)s', { width: %(w)d, height: %(h)d, spp: %(spp)d, frames: %(f)d, devices: [0, 0] }).then((r) => {
+  fs.writeFileSync('%(out)s', Buffer.from(r.accum.buffer));
+  console.log(JSON.stringify({ rays: r.rays }));
+}).catch((e) => { console.error(e); process.exit(1); });
+""" % dict(js=JS, w=width, h=height, spp=spp, f=frames, scene=S.scene_path("boxes"), out=str(tmp_path / "fs.f32"))
+    info = json.loads(node(script).strip().splitlines()[-1])
+    orc = O.OracleRenderer(scenes["boxes"], width, height)
+    orc.set_samples_per_pixel(spp)
+    sums = [np.zeros((height, width, 3), np.float32) for _ in range(2)]
+    clamped = np.zeros((height, width), bool)
+    for f in range(1, frames + 1):
+        before = orc.accum_rgb()
+        orc.render()
+        cur = orc.frame_f16.view(np.float16).astype(np.float32)[:, :, :3]
+        sums[(f - 1) % 2] += cur       # each renderer adds its frames in increasing order, in f32
+        w = np.float32(1) / np.float32(f + 1)
+        mean = before * (np.float32(1) - w) + cur * w
+        clamped |= ~((mean >= 0) & (mean <= 1)).all(axis=2)
+    total = sums[0] + sums[1]
+    with np.errstate(invalid="ignore"):
+        closed = np.minimum(np.maximum(total / np.float32(frames + 1), np.float32(0)), np.float32(1))
+    got = np.fromfile(tmp_path / "fs.f32", np.float32).reshape(height, width, 3)
+    assert np.array_equal(got, closed, equal_nan=True)
+    assert np.abs(got - orc.accum_rgb())[~clamped].max() <= 2e-6
     assert info["rays"] == int(orc.counters[0])
 
 

@@ -1,11 +1,14 @@
-"""rt_render_frames_noalloc (fixed device workspace, no hipMalloc) against rt_render_frames:
-bit-equal ids, rgba16float frame, accumulator and ray count, on two calls in a row that share
-the GPU's workspace, the second with a smaller image and another scene; then the limits."""
+"""rt_render_frames_noalloc (fixed device workspace, no hipMalloc) against rt_render_frames and
+against the CPU oracle: bit-equal ids, rgba16float frame, accumulator and ray count, on two calls
+in a row that share the GPU's workspace, the second with a smaller image and another scene; a
+scene whose traversal stack overflows into global memory, with no allocating call before it;
+then the limits."""
 import numpy as np
 import pytest
 
 from raytracer_amd import capi
 from raytracer_amd import scene as S
+from tests import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
 
@@ -34,6 +37,16 @@ def _same(a, b):
     assert int(a.read_counters()[0]) == int(b.read_counters()[0])
 
 
+def _same_as_oracle(ctx, scene, width, height, spp, frames):
+    orc = O.OracleRenderer(scene, width, height)
+    orc.set_samples_per_pixel(spp)
+    orc.render_frames(frames)
+    assert np.array_equal(ctx.read_primary_ids(), orc.ids)
+    assert _f16_equal(ctx.read_frame_f16(), orc.frame_f16)
+    assert np.array_equal(ctx.read_accum(), orc.accum_rgb())
+    assert int(ctx.read_counters()[0]) == int(orc.counters[0])
+
+
 def test_noalloc_matches_render_frames_twice_in_a_row(scenes):
     import torch
 
@@ -52,14 +65,44 @@ def test_noalloc_matches_render_frames_twice_in_a_row(scenes):
     small.render_frames_noalloc(1, 4)
     small.sync()
     _same(small, small_ref)
+    _same_as_oracle(small, scenes["boxes"], 72, 41, 2, 4)
     # and back to the first context: two more frames on top of the three
     free_before = torch.cuda.mem_get_info()[0]
     big.render_frames_noalloc(4, 2)
     big.sync()
     free_after = torch.cuda.mem_get_info()[0]
     _same(big, big_ref)
+    _same_as_oracle(big, scenes["suzanne"], 200, 120, 3, 5)
     assert free_after == free_before, "device memory in use changed across rt_render_frames_noalloc"
     for ctx in (big, big_ref, small, small_ref):
+        ctx.close()
+
+
+def test_noalloc_on_a_scene_whose_stack_overflows_into_global_memory():
+    """6,014 triangles stacked so that camera rays leave 18 entries on the traversal stack, more than the
+    12 the large-scene kernel keeps in LDS: the overflow area must have been made by rt_set_scene, since
+    no allocating render call comes first here; and once after a single-frame rt_render_frame, which
+    traces on a side stream with an overflow area of its own."""
+    import torch
+    from tests.synth import card_deck_scene
+
+    scene = card_deck_scene(3000)
+    spheres, tris = S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles)
+    width, height, spp = 64, 36, 2
+    for warm_up in (False, True):
+        ctx = capi.Context(width, height)
+        ctx.set_scene(spheres, tris)
+        ctx.set_uniforms(S.pack_uniforms(scene.camera, 1, width, height, spp))
+        first = 1
+        if warm_up:
+            ctx.render_frame()
+            ctx.sync()
+            first = 2
+        free_before = torch.cuda.mem_get_info()[0]
+        ctx.render_frames_noalloc(first, 4 - first)
+        ctx.sync()
+        assert torch.cuda.mem_get_info()[0] == free_before
+        _same_as_oracle(ctx, scene, width, height, spp, 3)
         ctx.close()
 
 
