@@ -68,7 +68,13 @@ typedef enum rt_tuning {
                                   one-thread-per-pixel kernel */
     RT_TUNE_COALESCE_FRAMES = 12, /* rt_render_frame: most frames held back and launched as one batch while the GPU is
                                   busy with earlier ones (default 16); 0 or 1 = every call launches its frame */
-    RT_TUNE_END = 13           /* one past the last key */
+    RT_TUNE_MIGRATE_LANES = 13, /* once a launch's work queues are empty, a wave that is down to this many live lanes
+                                  hands them to other waves of its block and exits; 0 (default) = every lane finishes in the
+                                  wave that started its pixel.  Only in builds with -DRT_MIGRATE=1, ignored otherwise */
+    RT_TUNE_TILE_ORDER = 14,   /* 1 (default): a launch hands out first the 8x8 tiles whose longest pixel took the most
+                                  rays in the previous launch, so that what is started last is short (frames of 4 samples per pixel or more);
+                                  0 = image order */
+    RT_TUNE_END = 15           /* one past the last key */
 } rt_tuning;
 
 /* Message of the last failure on the calling thread ("" if none). */
@@ -274,6 +280,15 @@ int rt_set_counting(rt_context *ctx, int enable);
  * finished, waiting to be shaded, idle, out of work); the rest 0.
  */
 int rt_debug_phase_cycles(rt_context *ctx, uint64_t out[16]);
+
+/*
+ * Diagnostic, no counterpart in the reference: the time line of the most recent instrumented launch of
+ * the persistent kernel (counting enabled), four values per wave of its grid: wall-clock ticks (100 MHz)
+ * at which the wave started, found the last work queue empty (0 if it never did) and ended, and the
+ * number of its lanes that still had a pixel in hand at that second moment.  Copies at most max_values
+ * values into `out` (may be NULL) and stores the number available in *n_values.
+ */
+int rt_debug_wave_trace(rt_context *ctx, uint64_t *out, size_t max_values, size_t *n_values);
 
 /*
  * The reference's performance counter: performance_counters[0] accumulates

@@ -21,6 +21,8 @@ RT_TUNE_SHADE_NUM, RT_TUNE_LEAF_LANES, RT_TUNE_BLOCKS_PER_CU, RT_TUNE_BATCH_FRAM
 RT_TUNE_REFILL_LANES = 5
 RT_TUNE_MAX_STACK = 11
 RT_TUNE_COALESCE_FRAMES = 12
+RT_TUNE_MIGRATE_LANES = 13
+RT_TUNE_TILE_ORDER = 14
 RT_TUNE_MAX_LEAF, RT_TUNE_TRI_COST_X10, RT_TUNE_LDS_STATE, RT_TUNE_OVERLAP_FRAMES, RT_TUNE_SHADE_WAIT = 6, 7, 8, 9, 10
 
 # name -> (restype, argtypes); must list every symbol include/rt_hip.h declares
@@ -41,6 +43,7 @@ SYMBOLS = {
     "rt_render_frames": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "rt_render_frames_noalloc": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "rt_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_debug_wave_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rt_sync": (C.c_int, [C.c_void_p]),
     "rt_last_render_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "rt_last_render_frames": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
@@ -212,6 +215,15 @@ class Context:
         out = np.zeros(16, dtype=np.uint64)
         _check(self.lib.rt_read_counters(self.handle, _ptr(out)))
         return out
+
+    def wave_trace(self) -> np.ndarray:
+        """(waves, 4) uint64: start, queues-empty, end (100 MHz ticks), live lanes at queues-empty."""
+        n = C.c_size_t()
+        _check(self.lib.rt_debug_wave_trace(self.handle, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint64)
+        if n.value:
+            _check(self.lib.rt_debug_wave_trace(self.handle, _ptr(out), n.value, C.byref(n)))
+        return out.reshape(-1, 4)
 
     def take_triangle_tests(self) -> int:
         v = C.c_uint32()

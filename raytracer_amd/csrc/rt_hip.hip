@@ -186,6 +186,42 @@ struct LdsPark {
     __device__ float get(int slot) const { return slot < NLDS ? base[slot * BLOCK] : regs[slot - NLDS]; }
 };
 
+// ---------------------------------------------------------------------------
+// Lane migration between the waves of a block ("tail compaction").
+//
+// When the work queues of a launch have run out, a wave keeps running until the last of its lanes has
+// finished its pixel, at full cost per instruction however few lanes are left.  So a wave that is down
+// to a few live lanes hands them over: it writes their registers into the LDS columns of its own dead
+// lanes, publishes which lanes are up for adoption and exits; waves of the same block with dead lanes
+// adopt them, a lane taking over the LDS column (traversal stack, parked state) of the lane it adopts
+// in place.  A path's state never changes, only the lane and wave that execute it, so results are
+// unaffected.  The header below lives in LDS, one per block.
+//   alive        waves that have neither exited nor committed to donating; the last one never donates
+//                and leaves only once nothing is left to adopt
+//   in_progress  donors between their commitment and the publication of their lanes
+//   dead[w]      lanes without work in wave w, as last published by it (receiving capacity, a hint)
+//   orig[w]      lanes of donor wave w that were live when it donated;  avail[w]  those not adopted yet
+// Lanes of one wave never pass values to each other through LDS here: the compiler is free to run the
+// two sides of "if (dead) write; if (live) read" in either order.
+// ---------------------------------------------------------------------------
+#ifndef RT_MIGRATE
+#define RT_MIGRATE 0 // measured: shortens a single-frame launch by 3 % and costs 3 % in long launches (five more spilled VGPRs)
+#endif
+struct MigrateHeader {
+    unsigned int alive, in_progress;
+    unsigned int dead[4];
+    unsigned long long orig[4], avail[4];
+};
+
+__device__ inline unsigned long long lanes_below(int lane) { return (1ull << lane) - 1ull; }
+
+// Position of the r-th (0-based) set bit of m.
+__device__ inline int nth_set_bit(unsigned long long m, int r)
+{
+    for (int k = 0; k < r; k++) m &= m - 1ull;
+    return __builtin_ctzll(m);
+}
+
 __device__ inline uint32_t wave_sum(uint32_t v)
 {
 #pragma unroll
@@ -198,6 +234,7 @@ struct FrameBuffers {
     uint16_t *frame_f16; // width*height*4 half bits
     int32_t *ids;        // width*height
     unsigned long long *counters;
+    unsigned long long *wave_trace; // instrumented launches only (may be null): 4 values per wave of the grid, see rt_debug_wave_trace
 };
 
 // rgba16float store + accumulator.wgsl:44-68 for one pixel.
@@ -301,6 +338,7 @@ struct SchedParams {
     int sdone_lanes;  // finish shadow rays when at least this many lanes wait for it (or no lane is traversing)
     int refill_lanes; // fetch new pixels when at least this many lanes are idle (or the whole wave is)
     int shade_wait;   // shade anyway once finished lanes have waited this many traversal turns (0: never)
+    int migrate_lanes; // once the queues are empty, a wave down to this many live lanes hands them to other waves of its block (0: never)
 };
 
 struct BatchParams {
@@ -312,7 +350,47 @@ struct BatchParams {
     int32_t *ids;         // [height * width] where the last batch frame's primary-hit ids go: the context's id
                           // plane, or a staging plane that the accumulate kernel copies from (overlapped frames)
     bool copy_ids;        // accumulate kernel: copy `ids` into the context's id plane
+    // Hand-out order of the tiles (see order_tiles_kernel): position p of queue q is tile tile_order[q_first + p]
+    // (identity when null); tile_cost, when not null, collects per tile the cost of its most expensive unit in this launch.
+    const uint32_t *tile_order;
+    unsigned int *tile_cost;
 };
+
+// The LDS column of a lane (its park slots, then its stack entries) addressed as dwords, and the
+// register image of a path that is handed from one lane to another through such columns.
+template <class CFG>
+struct LaneColumn {
+    using Entry = typename std::conditional<CFG::LINK16, int16_t, int32_t>::type;
+    static constexpr int kParkRegs = CFG::PARK < rt::kParkFloats ? rt::kParkFloats - CFG::PARK : 0;
+    static constexpr int kDwords = CFG::PARK + CFG::STACK * (int)sizeof(Entry) / 4;
+    static constexpr int kImage = 19 + kParkRegs;                      // dwords of register state per path
+    static constexpr int kColumnsPerImage = (kImage + kDwords - 1) / kDwords;
+    static constexpr int kMaxDonate = 64 / (1 + kColumnsPerImage);     // live lanes a donor can have: each needs that many dead ones
+    static_assert(sizeof(Entry) == 4 || CFG::STACK % 2 == 0, "16-bit stacks must fill whole dwords");
+
+    __device__ static uint32_t load(const Entry *st, const float *pk, int col, int i)
+    {
+        if (i < CFG::PARK) return rt::f2u(pk[i * kBlock + col]);
+        int j = i - CFG::PARK;
+        if (sizeof(Entry) == 4) return (uint32_t)st[j * kBlock + col];
+        return (uint32_t)(uint16_t)st[(2 * j) * kBlock + col] | ((uint32_t)(uint16_t)st[(2 * j + 1) * kBlock + col] << 16);
+    }
+    __device__ static void store(Entry *st, float *pk, int col, int i, uint32_t v)
+    {
+        if (i < CFG::PARK) { pk[i * kBlock + col] = rt::u2f(v); return; }
+        int j = i - CFG::PARK;
+        if (sizeof(Entry) == 4) { st[j * kBlock + col] = (Entry)v; return; }
+        st[(2 * j) * kBlock + col] = (Entry)(v & 0xffffu);
+        st[(2 * j + 1) * kBlock + col] = (Entry)(v >> 16);
+    }
+};
+
+__device__ inline unsigned long long uniform64(unsigned long long v)
+{
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
 
 template <class CFG, bool COUNT, bool FUSED>
 __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt::SceneView sc, rt::FrameParams fp, StripeMap sm,
@@ -332,6 +410,18 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
     stack.spill_stride = gridDim.x * kBlock;
     LdsPark<kBlock, PARK> park;
     park.base = lds_park + threadIdx.x;
+#if RT_MIGRATE
+    using Column = LaneColumn<CFG>;
+    __shared__ MigrateHeader mig;
+    const int wv = threadIdx.x >> 6;
+    int col = threadIdx.x; // the LDS column (and overflow column) of the path this lane runs; changes when it adopts one
+    if (threadIdx.x == 0) {
+        mig.alive = kBlock / 64;
+        mig.in_progress = 0u;
+        for (int w = 0; w < 4; w++) { mig.dead[w] = 0u; mig.orig[w] = 0ull; mig.avail[w] = 0ull; }
+    }
+    __syncthreads();
+#endif
 
     const uint32_t tiles_x = (uint32_t)(fp.width + 7) / 8u, tiles_y = (uint32_t)(local_rows + 7) / 8u;
     const uint32_t tiles_per_frame = tiles_x * tiles_y;
@@ -361,6 +451,8 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
     uint32_t occ_it = 0, occ_inner = 0, occ_leaf = 0, occ_sdone = 0, occ_ready = 0, occ_idle = 0, occ_dead = 0; // COUNT only: lanes per state, summed over traversal turns
     unsigned long long tc_inner = 0, tc_tri = 0, tc_sdone = 0, tc_shade = 0, tc_total = 0, tc0 = 0, tc_begin = 0; // COUNT only: wave cycles per phase
     if (COUNT) tc_begin = clock64();
+    unsigned long long tr_begin = 0, tr_exhausted = 0, tr_live_at_exhaustion = 0; // COUNT only: wall-clock ticks (100 MHz)
+    if (COUNT) tr_begin = wall_clock64();
     bool exhausted = false; // wave-uniform: the global counter has run out
 
     for (;;) {
@@ -372,6 +464,11 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
             int px = (int)((tile % tiles_x) * 8u + (slot & 7u));
             int ly = (int)((tile / tiles_x) * 8u + (slot >> 3));
             int py = stripe_global_row(sm, ly);
+            // The cost of a tile, for the order in which the next launch hands tiles out: the most rays any of its
+            // units took (a launch ends when its last unit does, so a tile with one long pixel must go early however
+            // cheap the rest of it is).  Units of the launch's first frame only: one frame's costs are as good as all,
+            // and with every unit reporting, thousands of lanes would hit the few tiles in hand at any moment.
+            if (bp.tile_cost && frame_k == 0u) atomicMax(bp.tile_cost + tile, rt::lane_unit_cost(L) + 1u);
             if (FUSED) store_pixel(fp, fb, px, py, color, rt::lane_primary_id(sc, park), bp.sum);
             else {
                 size_t lp = (size_t)ly * fp.width + px;
@@ -408,8 +505,11 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
                 uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
                 uint32_t n = base + rank; // position in the queue
                 if (L.mode == rt::kLaneNeedUnit && n < q_units) {
-                    uint32_t frame_k = n / (q_tiles * 64u), rest = n % (q_tiles * 64u);
-                    uint32_t tile = q_first + (rest >> 6), slot = rest & 63u;
+                    // positions count tile-major: all frames of the queue's first tile, then of its second, ...
+                    uint32_t group = n >> 6, slot = n & 63u;
+                    uint32_t tile_pos = group / bp.n_frames, frame_k = group % bp.n_frames;
+                    uint32_t tile = q_first + tile_pos;
+                    if (bp.tile_order) tile = bp.tile_order[tile];
                     int px = (int)((tile % tiles_x) * 8u + (slot & 7u));
                     int ly = (int)((tile / tiles_x) * 8u + (slot >> 3));
                     int py = stripe_global_row(sm, ly);
@@ -428,10 +528,128 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
                 // the next one; after leaving all of them behind there is no work left.
                 if (base + n_need >= q_units) {
                     my_queue = (my_queue + 1u) % kQueues;
-                    if (++queues_left == kQueues) exhausted = true;
+                    if (++queues_left == kQueues) {
+                        exhausted = true;
+                        if (COUNT) { tr_exhausted = wall_clock64(); tr_live_at_exhaustion = (unsigned long long)__popcll(__ballot(L.mode != rt::kLaneNeedUnit && L.mode != rt::kLaneDead)); }
+                    }
                 }
             }
         }
+#if RT_MIGRATE
+        if (sched.migrate_lanes > 0) {
+            if (exhausted) {
+                // ---- adopt lanes that other waves of the block have put up ------------------------------
+                for (int w = 0; w < 4; w++) {
+                    unsigned long long dead_mask = __ballot(L.mode == rt::kLaneDead);
+                    if (dead_mask == 0ull) break;
+                    unsigned long long av = uniform64(__hip_atomic_load(&mig.avail[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    if (av == 0ull) continue;
+                    int n_take = min(__popcll(av), __popcll(dead_mask));
+                    unsigned long long take = 0ull, rest = av;
+                    for (int k = 0; k < n_take; k++) { unsigned long long b = rest & (~rest + 1ull); take |= b; rest ^= b; }
+                    unsigned long long old = 0ull;
+                    if (lane == 0) old = atomicCAS(&mig.avail[w], av, av & ~take);
+                    old = uniform64(old);
+                    if (old != av) { w--; continue; } // another wave took some of them first: look again
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    int r = __popcll(dead_mask & lanes_below(lane));
+                    if (L.mode == rt::kLaneDead && r < n_take) {
+                        int from = nth_set_bit(take, r);
+                        int k = __popcll(mig.orig[w] & lanes_below(from)); // rank among the donor's live lanes
+                        // its registers are in the natural columns of the donor's dead lanes, rank for rank
+                        unsigned long long donor_dead = ~mig.orig[w];
+                        int src[Column::kColumnsPerImage];
+#pragma unroll
+                        for (int c = 0; c < Column::kColumnsPerImage; c++) src[c] = w * 64 + nth_set_bit(donor_dead, k * Column::kColumnsPerImage + c);
+                        uint32_t img[Column::kImage];
+#pragma unroll
+                        for (int i = 0; i < Column::kImage; i++) img[i] = Column::load(lds_stack, lds_park, src[i / Column::kDwords], i % Column::kDwords);
+                        L.unit = img[0]; L.rng = img[1]; L.bits = img[2];
+                        L.mode = (int32_t)(img[3] & 0xffu);
+                        stack.sp = (int)((img[3] >> 8) & 0xffu);
+                        col = (int)(img[3] >> 16);
+                        L.color = rt::mk3(rt::u2f(img[4]), rt::u2f(img[5]), rt::u2f(img[6]));
+                        L.light = rt::mk3(rt::u2f(img[7]), rt::u2f(img[8]), rt::u2f(img[9]));
+                        L.o = rt::mk3(rt::u2f(img[10]), rt::u2f(img[11]), rt::u2f(img[12]));
+                        L.d = rt::mk3(rt::u2f(img[13]), rt::u2f(img[14]), rt::u2f(img[15]));
+                        L.tmax = rt::u2f(img[16]); L.best_id = (int32_t)img[17]; L.cur = (int32_t)img[18];
+#pragma unroll
+                        for (int i = 0; i < Column::kParkRegs; i++) park.regs[i] = rt::u2f(img[19 + i]);
+                        L.rb = rt::make_raybox(L.o, L.d); // a function of the ray alone
+                        stack.base = lds_stack + col;
+                        park.base = lds_park + col;
+                        if (CFG::SPILL) stack.spill = spill + ((size_t)blockIdx.x * kBlock + col);
+                    }
+                }
+                unsigned long long live = __ballot(L.mode != rt::kLaneDead);
+                int n_live = __popcll(live);
+                if (n_live == 0) {
+                    // ---- leave, unless this is the block's last wave and lanes are on offer or about to be ----
+                    unsigned int before = 0u;
+                    if (lane == 0) { mig.dead[wv] = 0u; before = __hip_atomic_fetch_sub(&mig.alive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                    before = (unsigned int)__builtin_amdgcn_readfirstlane((int)before);
+                    if (before > 1u) break;
+                    while (__hip_atomic_load(&mig.in_progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(2);
+                    unsigned long long offered = 0ull;
+                    for (int w = 0; w < 4; w++) offered |= __hip_atomic_load(&mig.avail[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (uniform64(offered) == 0ull) break;
+                    if (lane == 0) __hip_atomic_fetch_add(&mig.alive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    continue; // adopt them on the next turn
+                }
+                if (lane == 0 && mig.dead[wv] != (unsigned int)(64 - n_live)) mig.dead[wv] = (unsigned int)(64 - n_live);
+                // ---- hand over the remaining lanes when they are few and others have room for them -----
+                if (n_live <= sched.migrate_lanes && n_live <= Column::kMaxDonate) {
+                    unsigned int room = 0u;
+                    for (int w = 0; w < 4; w++)
+                        if (w != wv) room += __hip_atomic_load(&mig.dead[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    room = (unsigned int)__builtin_amdgcn_readfirstlane((int)room);
+                    unsigned int before = 0u;
+                    if (room >= (unsigned int)n_live && lane == 0) {
+                        __hip_atomic_fetch_add(&mig.in_progress, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        before = __hip_atomic_fetch_sub(&mig.alive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (before <= 1u) { // the last wave stays
+                            __hip_atomic_fetch_add(&mig.alive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_sub(&mig.in_progress, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                    before = (unsigned int)__builtin_amdgcn_readfirstlane((int)before);
+                    if (before > 1u) {
+                        // the natural columns of this wave's dead lanes are free (a lane that runs an adopted
+                        // path uses the column it adopted): they take the register images, the k-th live
+                        // lane's going to the k-th dead lane's column (both sides work that out from the mask
+                        // of live lanes alone, nothing is passed between the lanes of this wave)
+                        if (L.mode != rt::kLaneDead) {
+                            int k = __popcll(live & lanes_below(lane));
+                            int dst_col[Column::kColumnsPerImage];
+#pragma unroll
+                            for (int c = 0; c < Column::kColumnsPerImage; c++) dst_col[c] = wv * 64 + nth_set_bit(~live, k * Column::kColumnsPerImage + c);
+                            uint32_t img[Column::kImage];
+                            img[0] = L.unit; img[1] = L.rng; img[2] = L.bits;
+                            img[3] = (uint32_t)L.mode | ((uint32_t)stack.sp << 8) | ((uint32_t)col << 16);
+                            img[4] = rt::f2u(L.color.x); img[5] = rt::f2u(L.color.y); img[6] = rt::f2u(L.color.z);
+                            img[7] = rt::f2u(L.light.x); img[8] = rt::f2u(L.light.y); img[9] = rt::f2u(L.light.z);
+                            img[10] = rt::f2u(L.o.x); img[11] = rt::f2u(L.o.y); img[12] = rt::f2u(L.o.z);
+                            img[13] = rt::f2u(L.d.x); img[14] = rt::f2u(L.d.y); img[15] = rt::f2u(L.d.z);
+                            img[16] = rt::f2u(L.tmax); img[17] = (uint32_t)L.best_id; img[18] = (uint32_t)L.cur;
+#pragma unroll
+                            for (int i = 0; i < Column::kParkRegs; i++) img[19 + i] = rt::f2u(park.regs[i]);
+#pragma unroll
+                            for (int i = 0; i < Column::kImage; i++) Column::store(lds_stack, lds_park, dst_col[i / Column::kDwords], i % Column::kDwords, img[i]);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // images, stacks (LDS and overflow columns) before the offer
+                        if (lane == 0) {
+                            mig.orig[wv] = live;
+                            mig.dead[wv] = 0u;
+                            __hip_atomic_store(&mig.avail[wv], live, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_sub(&mig.in_progress, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        L.mode = rt::kLaneDead;
+                        break;
+                    }
+                }
+            }
+        } else
+#endif
         if (__ballot(L.mode != rt::kLaneDead) == 0ull) break;
 
         // ---- traversal steps ----------------------------------------------------------------
@@ -496,6 +714,10 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
         if (COUNT) tc_shade += clock64() - tc0;
     }
     if (COUNT) tc_total = clock64() - tc_begin;
+    if (COUNT && fb.wave_trace && lane == 0) {
+        unsigned long long *t = fb.wave_trace + 4 * ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+        t[0] = tr_begin; t[1] = tr_exhausted; t[2] = wall_clock64(); t[3] = tr_live_at_exhaustion;
+    }
 
     uint32_t total = wave_sum(n_rays.calls), total_trav = wave_sum(n_rays.traversed);
     if (lane == 0 && total) {
@@ -574,6 +796,50 @@ __global__ void finish_sums_kernel(float *planes, size_t n, float divisor)
     if (i < n) planes[i] = fminf(fmaxf(planes[i] / divisor, 0.0f), 1.0f);
 }
 
+// Hand-out order of a launch's tiles: within each work queue, the tiles that held the longest units of the
+// previous launch come first.  A launch ends when its last unit ends, and a unit is serial work (the
+// samples of a pixel-frame share one random stream): whatever is handed out last should be short.
+// One block per queue.  cost: per tile, the cost of its most expensive unit in the previous launch (rt::lane_unit_cost + 1;
+// all zero before the first);
+// cls: scratch of one entry per tile; order: out, a permutation of each queue's tiles, most expensive
+// of 256 cost classes first.  Every tile's cost is read exactly once, so the result is a permutation
+// whatever the values are; the order within a class is arbitrary, which no result depends on.
+__global__ __launch_bounds__(256) void order_tiles_kernel(const unsigned int *cost, uint32_t *cls, uint32_t *order, uint32_t tiles_per_frame)
+{
+    __shared__ unsigned int top, bins[256];
+    const uint32_t q = blockIdx.x;
+    const uint32_t q_first = (uint32_t)((uint64_t)tiles_per_frame * q / kQueues);
+    const uint32_t q_tiles = (uint32_t)((uint64_t)tiles_per_frame * (q + 1u) / kQueues) - q_first;
+    if (threadIdx.x == 0) top = 0u;
+    bins[threadIdx.x] = 0u;
+    __syncthreads();
+    unsigned int mine = 0u;
+    for (uint32_t i = threadIdx.x; i < q_tiles; i += 256u) {
+        unsigned int c = cost[q_first + i];
+        cls[q_first + i] = c;
+        mine = max(mine, c);
+    }
+    atomicMax(&top, mine);
+    __syncthreads();
+    const unsigned int most = top;
+    for (uint32_t i = threadIdx.x; i < q_tiles; i += 256u) {
+        unsigned int c = cls[q_first + i];
+        unsigned int k = most ? 255u - (unsigned int)((uint64_t)c * 255u / most) : 0u; // 0 = most expensive
+        cls[q_first + i] = k;
+        atomicAdd(&bins[k], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { // exclusive prefix sums: where each class starts
+        unsigned int run = 0u;
+        for (int k = 0; k < 256; k++) { unsigned int n = bins[k]; bins[k] = run; run += n; }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < q_tiles; i += 256u) {
+        unsigned int at = atomicAdd(&bins[cls[q_first + i]], 1u);
+        order[q_first + at] = q_first + i;
+    }
+}
+
 __global__ void fill_i32_kernel(int32_t *p, int32_t v, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -637,7 +903,7 @@ struct rt_context {
     void *scratch = nullptr; // this device's copy of the fixed workspace (rt_render_frames_noalloc)
     bool no_alloc = false;   // set for the duration of an rt_render_frames_noalloc call
 
-    FrameBuffers fb{nullptr, nullptr, nullptr, nullptr};
+    FrameBuffers fb{nullptr, nullptr, nullptr, nullptr, nullptr};
 
     // scene
     rt::BuiltScene host_scene;
@@ -674,6 +940,12 @@ struct rt_context {
     bool slot_used[kMaxSlots] = {false, false, false, false};
     int32_t *d_spill[1 + kMaxSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // traversal stack overflow, per stream (main, side streams)
     size_t spill_bytes[1 + kMaxSlots] = {0, 0, 0, 0, 0};
+    // Tile hand-out order, per stream (main, side streams): rays per tile of the stream's last two launches
+    // (one being written, one being read), the order made from it, and scratch of the ordering kernel.
+    unsigned int *d_tile_cost[1 + kMaxSlots][2] = {};
+    uint32_t *d_tile_order[1 + kMaxSlots] = {}, *d_tile_cls[1 + kMaxSlots] = {};
+    int tile_cost_phase[1 + kMaxSlots] = {};
+    int tune_tile_order = 1;
     int next_slot = 0;
     // Submission coalescing of rt_render_frame (see flush_pending): frames pending_first ..
     // pending_first + pending_n - 1 have been asked for and not launched yet.
@@ -690,10 +962,12 @@ struct rt_context {
             if (s == aux[k]) return 1 + k;
         return 0;
     }
+    size_t wave_trace_len = 0, wave_trace_used = 0; // fb.wave_trace: values allocated / written by the last instrumented launch
     float *d_row_staging = nullptr; // device block the host-memory row exchange (rt_read_owned_rows / rt_write_rows) goes through
     size_t row_staging_bytes = 0;
     int tune_max_stack = 64;
     int tune_shade_wait = 12;
+    int tune_migrate = RT_MIGRATE ? 16 : 0;
     bool debug_view = false;    // opt-in extension: uniforms.debugEnabled draws the triangles' normal markers (brute-force kernel)
     bool sphere_lights = false; // opt-in extension: emissive spheres are sampled too (one-thread-per-pixel kernel)
     int tune_shade_num = 2, tune_leaf_lanes = 12, tune_blocks_per_cu = 0, tune_batch = 0, tune_sdone_lanes = 2, tune_refill_lanes = 0, tune_max_leaf = 4, tune_tri_cost_x10 = 12, tune_lds_state = RT_LDS_PARK;
@@ -746,6 +1020,26 @@ int launch_tiles(rt_context *c, const rt::FrameParams &fp, bool sum)
 
 int ensure_spill(rt_context *c, int which, hipStream_t stream, uint64_t blocks);
 
+uint32_t tiles_per_frame_of(const rt_context *c)
+{
+    return (uint32_t)((c->width + 7) / 8) * (uint32_t)((c->local_rows + 7) / 8);
+}
+
+// Buffers of the tile hand-out order for stream `which` (0 main, 1.. side streams); costs start at zero.
+int ensure_tile_order(rt_context *c, int which)
+{
+    size_t tiles = tiles_per_frame_of(c);
+    if (tiles == 0 || c->d_tile_cls[which]) return RT_OK; // the last one made
+    for (int k = 0; k < 2; k++)
+        if (!c->d_tile_cost[which][k]) {
+            RT_HIP_CHECK(hipMalloc((void **)&c->d_tile_cost[which][k], tiles * sizeof(unsigned int)));
+            RT_HIP_CHECK(hipMemset(c->d_tile_cost[which][k], 0, tiles * sizeof(unsigned int)));
+        }
+    if (!c->d_tile_order[which]) RT_HIP_CHECK(hipMalloc((void **)&c->d_tile_order[which], tiles * sizeof(uint32_t)));
+    RT_HIP_CHECK(hipMalloc((void **)&c->d_tile_cls[which], tiles * sizeof(uint32_t)));
+    return RT_OK;
+}
+
 template <class CFG, bool COUNT, bool FUSED>
 int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchParams &bp, unsigned int *counter, hipStream_t stream)
 {
@@ -768,13 +1062,41 @@ int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchPar
         if (rc) return rc;
     }
     int32_t *spill = CFG::SPILL ? c->d_spill[c->stream_index(stream)] : nullptr;
+    if (COUNT) {
+        size_t need = (size_t)blocks * (kBlock / 64) * 4;
+        if (c->wave_trace_len < need) {
+            RT_HIP_CHECK(hipStreamSynchronize(stream));
+            (void)hipFree(c->fb.wave_trace);
+            c->fb.wave_trace = nullptr;
+            c->wave_trace_len = 0;
+            RT_HIP_CHECK(hipMalloc((void **)&c->fb.wave_trace, need * sizeof(unsigned long long)));
+            c->wave_trace_len = need;
+        }
+        c->wave_trace_used = need;
+    }
     // Starting a pixel (seed, jitter, camera ray) is long code: with few samples per pixel it runs
     // often, so more idle lanes are collected before a refill (measured optimum per spp).
     int refill = c->tune_refill_lanes;
     if (refill <= 0) refill = fp.spp <= 1u ? 32 : fp.spp <= 2u ? 24 : fp.spp <= 4u ? 16 : fp.spp <= 8u ? 8 : 4;
-    SchedParams sched{c->tune_shade_num, c->tune_leaf_lanes, c->tune_sdone_lanes, refill, c->tune_shade_wait};
+    SchedParams sched{c->tune_shade_num, c->tune_leaf_lanes, c->tune_sdone_lanes, refill, c->tune_shade_wait, c->tune_migrate};
+    BatchParams bpl = bp;
+    const int which = c->stream_index(stream);
+    // (not for frames of a few samples per pixel: their units are short, so is the end of their launches, and the
+    // bookkeeping costs more than it saves: +28 % on single 1-spp frames)
+    if (c->tune_tile_order && c->d_tile_cls[which] && fp.spp >= 4u) {
+        // the tiles that cost most in this stream's previous launch go first; this launch's costs go to the other buffer
+        const uint32_t tiles_per_frame = tiles_per_frame_of(c);
+        unsigned int *prev = c->d_tile_cost[which][c->tile_cost_phase[which]], *cur = c->d_tile_cost[which][c->tile_cost_phase[which] ^ 1];
+        c->tile_cost_phase[which] ^= 1;
+        RT_HIP_CHECK(hipMemsetAsync(cur, 0, (size_t)tiles_per_frame * sizeof(unsigned int), stream));
+        hipLaunchKernelGGL(order_tiles_kernel, dim3(kQueues), dim3(256), 0, stream, prev, c->d_tile_cls[which], c->d_tile_order[which],
+                           tiles_per_frame);
+        RT_HIP_CHECK(hipGetLastError());
+        bpl.tile_order = c->d_tile_order[which];
+        bpl.tile_cost = cur;
+    }
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, c->view, fp, c->sm, c->local_rows, c->fb,
-                       bp, counter, sched, spill);
+                       bpl, counter, sched, spill);
     RT_HIP_CHECK(hipGetLastError());
     return RT_OK;
 }
@@ -869,6 +1191,8 @@ int ensure_slots(rt_context *c)
         if (!c->trace_done[k]) RT_HIP_CHECK(hipEventCreateWithFlags(&c->trace_done[k], hipEventDisableTiming));
         if (!c->slot_free[k]) RT_HIP_CHECK(hipEventCreateWithFlags(&c->slot_free[k], hipEventDisableTiming));
         if (!c->d_slot[k]) RT_HIP_CHECK(hipMalloc((void **)&c->d_slot[k], std::max<size_t>(local_px, 1) * sizeof(uint2)));
+        int rc = ensure_tile_order(c, 1 + k);
+        if (rc) return rc;
         RT_HIP_CHECK(hipMalloc((void **)&c->d_slot_ids[k], px * sizeof(int32_t)));
     }
     return RT_OK;
@@ -1002,6 +1326,15 @@ int check_ready(rt_context *c)
 
 static int render_frames_impl(rt_context *c, uint32_t first_frame_index, uint32_t n_frames, uint32_t stride, bool sum);
 
+// Whether frames go through the persistent kernel: the default mode without the extensions that only the
+// one-thread-per-pixel kernels implement, a tree its stack can hold, and no more samples per pixel-frame than
+// its lanes count (4096; the reference's own limit is 16, src/webgpu-renderer.ts:233).
+static bool persistent_path(const rt_context *c)
+{
+    return c->mode == RT_MODE_BVH && !c->sphere_lights && !debug_view_active(c) &&
+           persistent_stack_need(c) <= (uint32_t)c->tune_max_stack && c->uniforms[16] <= (float)rt::kMaxLaneSamples;
+}
+
 // Submission coalescing.  rt_render_frame is the reference's fire-and-forget submit: one frame per
 // call, called back to back by a render loop.  A launch of one frame ends with a tail in which lanes
 // finish their last pixel while the others idle, so frames submitted while the GPU is still busy
@@ -1096,6 +1429,10 @@ int rt_create(int device, int width, int height, int stripe_rows, int stripe_ind
     hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, c->stream, c->fb.ids, -2, px);
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess)
         return cleanup(fail(RT_ERR_DEVICE, std::string("rt_create: ") + hipGetErrorString(e)));
+    {
+        int rc = ensure_tile_order(c, 0); // here, not at the first launch: rt_render_frames_noalloc must find it made
+        if (rc) return cleanup(rc);
+    }
     *out = c;
     return RT_OK;
 }
@@ -1115,7 +1452,11 @@ void rt_destroy(rt_context *c)
     for (hipEvent_t e : c->flush_done)
         if (e) (void)hipEventDestroy(e);
     for (int32_t *p : c->d_spill) (void)hipFree(p);
-    (void)hipFree(c->d_work); (void)hipFree(c->d_batch); (void)hipFree(c->d_row_staging);
+    for (int k = 0; k <= rt_context::kMaxSlots; k++) {
+        (void)hipFree(c->d_tile_cost[k][0]); (void)hipFree(c->d_tile_cost[k][1]);
+        (void)hipFree(c->d_tile_order[k]); (void)hipFree(c->d_tile_cls[k]);
+    }
+    (void)hipFree(c->d_work); (void)hipFree(c->d_batch); (void)hipFree(c->d_row_staging); (void)hipFree(c->fb.wave_trace);
     (void)hipFree(c->fb.accum); (void)hipFree(c->fb.frame_f16); (void)hipFree(c->fb.ids); (void)hipFree(c->fb.counters);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
@@ -1279,6 +1620,8 @@ int rt_set_tuning(rt_context *c, int key, int value)
     case RT_TUNE_COALESCE_FRAMES: if (value < 0 || value > 256) return fail(RT_ERR_INVALID, "coalesce_frames out of range"); c->tune_coalesce = value; break;
     case RT_TUNE_MAX_STACK: if (value < 1 || value > (int)kMaxStackEntries) return fail(RT_ERR_INVALID, "max_stack out of range"); c->tune_max_stack = value; break;
     case RT_TUNE_SHADOW_DONE_LANES: if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "shadow_done_lanes out of range"); c->tune_sdone_lanes = value; break;
+    case RT_TUNE_TILE_ORDER: if (value < 0 || value > 1) return fail(RT_ERR_INVALID, "tile_order must be 0 or 1"); c->tune_tile_order = value; break;
+    case RT_TUNE_MIGRATE_LANES: if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "migrate_lanes out of range"); c->tune_migrate = RT_MIGRATE ? value : 0; break;
     default: return fail(RT_ERR_INVALID, "unknown tuning key");
     }
     return RT_OK;
@@ -1294,7 +1637,7 @@ static int render_frames_impl(rt_context *c, uint32_t first_frame_index, uint32_
     RT_HIP_CHECK(hipSetDevice(c->device));
     if ((rc = ensure_padding_covers_camera(c))) return rc;
     RT_HIP_CHECK(hipEventRecord(c->ev_start, c->stream));
-    if (c->mode == RT_MODE_BVH && !c->sphere_lights && !debug_view_active(c) && persistent_stack_need(c) <= (uint32_t)c->tune_max_stack) {
+    if (persistent_path(c)) {
         if ((rc = launch_persistent(c, first_frame_index, n_frames, stride, sum))) return rc;
     } else {
         for (uint32_t k = 0; k < n_frames; k++) {
@@ -1388,8 +1731,7 @@ int rt_render_frame(rt_context *c)
     if (rc) return rc;
     uint32_t frame = (uint32_t)c->uniforms[12];
     if (frame >= (1u << 24)) return fail(RT_ERR_INVALID, "frame index beyond 2^24 is not exact in the f32 uniform");
-    bool coalesce = c->tune_coalesce > 1 && c->mode == RT_MODE_BVH && !c->sphere_lights && !debug_view_active(c) && !c->counting &&
-                    persistent_stack_need(c) <= (uint32_t)c->tune_max_stack;
+    bool coalesce = c->tune_coalesce > 1 && !c->counting && persistent_path(c);
     if (!coalesce) {
         RT_FLUSH_PENDING(c);
         return render_frames_impl(c, frame, 1, 1, false);
@@ -1517,6 +1859,21 @@ int rt_debug_phase_cycles(rt_context *c, uint64_t out[16])
     RT_HIP_CHECK(hipMemcpyAsync(tmp, c->fb.counters + 16, sizeof tmp, hipMemcpyDeviceToHost, c->stream));
     RT_HIP_CHECK(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 16; i++) out[i] = tmp[i];
+    return RT_OK;
+}
+
+int rt_debug_wave_trace(rt_context *c, uint64_t *out, size_t max_values, size_t *n_values)
+{
+    if (!c || !n_values) return fail(RT_ERR_INVALID, "null argument");
+    RT_FLUSH_PENDING(c);
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    *n_values = c->wave_trace_used;
+    if (!out || max_values == 0 || c->wave_trace_used == 0) return RT_OK;
+    size_t n = std::min(max_values, c->wave_trace_used);
+    RT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (hipStream_t s2 : c->aux)
+        if (s2) RT_HIP_CHECK(hipStreamSynchronize(s2));
+    RT_HIP_CHECK(hipMemcpy(out, c->fb.wave_trace, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

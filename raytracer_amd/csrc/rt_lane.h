@@ -58,7 +58,7 @@ struct Lane {
     // pixel / frame
     uint32_t unit;        // (frame, pixel) unit number handed out by the scheduler
     uint32_t rng;
-    uint32_t bits;        // sample (bits 0-15), bounce (16-23), flags (24-27), see below
+    uint32_t bits;        // sample (bits 0-11), bounce (12-19), flags (20-23), cost so far (24-31), see below
     // path
     f3 color, light;
     // ray in flight
@@ -104,14 +104,21 @@ RT_HD f3 park_get3(const Park &park, int slot)
     return mk3(park.get(slot), park.get(slot + 1), park.get(slot + 2));
 }
 
-constexpr uint32_t kBitSpec = 1u << 24;     // is_specular_bounce of the path
-constexpr uint32_t kBitAnyhit = 1u << 25;   // the ray in flight is a shadow ray
-constexpr uint32_t kBitHasEm = 1u << 26;    // L.em is to be added to light
-constexpr uint32_t kBitContinue = 1u << 27; // the path goes on after the shadow ray
+constexpr uint32_t kSampleMask = 0xfffu;    // samples per pixel-frame the lane state machine can count: up to kMaxLaneSamples
+constexpr uint32_t kMaxLaneSamples = kSampleMask + 1u;
+constexpr uint32_t kBounceShift = 12;       // 8 bits
+constexpr uint32_t kBitSpec = 1u << 20;     // is_specular_bounce of the path
+constexpr uint32_t kBitAnyhit = 1u << 21;   // the ray in flight is a shadow ray
+constexpr uint32_t kBitHasEm = 1u << 22;    // L.em is to be added to light
+constexpr uint32_t kBitContinue = 1u << 23; // the path goes on after the shadow ray
+// Bits 24-31: the bounces of the pixel-frame's finished samples, added up and saturating at 255: what the
+// unit has cost so far (two rays per bounce), for the scheduler (lane_unit_cost).
+constexpr uint32_t kCostShift = 24, kCostMask = 0xffu << kCostShift;
 
-RT_HD uint32_t lane_sample(const Lane &L) { return L.bits & 0xffffu; }
-RT_HD uint32_t lane_bounce(const Lane &L) { return (L.bits >> 16) & 0xffu; }
+RT_HD uint32_t lane_sample(const Lane &L) { return L.bits & kSampleMask; }
+RT_HD uint32_t lane_bounce(const Lane &L) { return (L.bits >> kBounceShift) & 0xffu; }
 RT_HD bool lane_flag(const Lane &L, uint32_t bit) { return (L.bits & bit) != 0u; }
+RT_HD uint32_t lane_unit_cost(const Lane &L) { return L.bits >> kCostShift; }
 RT_HD void lane_set_flag(Lane &L, uint32_t bit, bool on) { L.bits = on ? (L.bits | bit) : (L.bits & ~bit); }
 // primary-hit id of the pixel (-1 on a miss), valid once the camera ray has been shaded
 template <class Park>
@@ -400,6 +407,8 @@ RT_HD void lane_end_path(const FrameParams &fp, Lane &L, Park &park, RayCounts &
 {
     f3 total = add(park_get3(park, kParkTotal), L.light);
     uint32_t sample = lane_sample(L) + 1u;
+    uint32_t cost = lane_unit_cost(L) + lane_bounce(L);
+    cost = (cost > 255u ? 255u : cost) << kCostShift;
     if (sample < fp.spp && (int32_t)f2u(park.get(kParkPrimId)) == kNoHit) {
         // The camera ray missed everything, and every remaining sample starts on that same ray: each
         // is ray_all -> miss -> light = 0.4 * color with color = 1 (raytracer_compute.wgsl:198-202),
@@ -413,7 +422,7 @@ RT_HD void lane_end_path(const FrameParams &fp, Lane &L, Park &park, RayCounts &
     }
     park_put3(park, kParkTotal, total);
     if (sample < fp.spp) {
-        L.bits = sample; // bounce 0, no flags: not specular, closest-hit result
+        L.bits = sample | cost; // bounce 0, no flags: not specular, closest-hit result
         L.color = mk3(1.0f, 1.0f, 1.0f);
         L.light = mk3(0.0f, 0.0f, 0.0f);
         L.o = fp.cam_pos;
@@ -424,6 +433,7 @@ RT_HD void lane_end_path(const FrameParams &fp, Lane &L, Park &park, RayCounts &
         L.mode = kLaneShadeClosest;
         n_rays.calls++;
     } else {
+        L.bits = (L.bits & ~kCostMask) | cost;
         L.mode = kLanePixelDone;
     }
 }
@@ -455,6 +465,7 @@ RT_HD void lane_empty_pixel(Lane &L, Park &park)
 {
     park_put3(park, kParkTotal, mk3(0.0f, 0.0f, 0.0f));
     park.put(kParkPrimId, u2f((uint32_t)kNoHit));
+    L.bits = 0u;
     L.mode = kLanePixelDone;
 }
 
@@ -466,7 +477,7 @@ RT_HD void lane_shade_closest(const SceneView &sc, const FrameParams &fp, Lane &
     int32_t id = (L.best_id == kNoHit) ? -1 : L.best_id;
     float t = L.tmax;
     uint32_t bounce = lane_bounce(L);
-    if ((L.bits & 0xffffffu) == 0u) { // first bounce of the first sample: remember the camera ray's hit
+    if ((L.bits & ~kCostMask) == 0u) { // first bounce of the first sample: remember the camera ray's hit
         park.put(kParkPrimT, L.tmax);
         park.put(kParkPrimId, u2f((uint32_t)L.best_id));
     }
@@ -493,7 +504,7 @@ RT_HD void lane_shade_closest(const SceneView &sc, const FrameParams &fp, Lane &
         bool alive = finish_bounce(hit, bounce, no, nd, L.color, em, has_em, spec, L.rng);
         bounce++;
         bool cont = alive && bounce < fp.max_bounces;
-        L.bits = (L.bits & 0xffffu) | (bounce << 16) | (spec ? kBitSpec : 0u) | (has_em ? kBitHasEm : 0u) |
+        L.bits = (L.bits & (kSampleMask | kCostMask)) | (bounce << kBounceShift) | (spec ? kBitSpec : 0u) | (has_em ? kBitHasEm : 0u) |
                  (cont ? kBitContinue : 0u);
         if (shadow) {
             park_put3(park, kParkNextO, no);

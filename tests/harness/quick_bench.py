@@ -11,6 +11,8 @@ for k, name_ in enumerate(['SHADE', 'LEAF', 'BPC', 'BATCH', 'SDONE', 'REFILL', '
     if 'RT_' + name_ in os.environ: ctx.set_tuning(k, int(os.environ['RT_' + name_]))
 if 'RT_SHADEWAIT' in os.environ: ctx.set_tuning(10, int(os.environ['RT_SHADEWAIT']))
 if 'RT_COALESCE' in os.environ: ctx.set_tuning(12, int(os.environ['RT_COALESCE']))
+if 'RT_TILEORDER' in os.environ: ctx.set_tuning(14, int(os.environ['RT_TILEORDER']))
+if 'RT_MIGRATE' in os.environ: ctx.set_tuning(13, int(os.environ['RT_MIGRATE']))
 ctx.set_scene(S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles))
 ctx.set_uniforms(S.pack_uniforms(sc.camera, 1, W, H, spp))
 ctx.render_frames(1, 1); ctx.sync()

@@ -108,6 +108,7 @@ def test_batched_frames_bit_exact(scenes, batch):
     ((capi.RT_TUNE_BLOCKS_PER_CU, 1),),
     ((capi.RT_TUNE_SHADE_WAIT, 0), (capi.RT_TUNE_REFILL_LANES, 64)),
     ((capi.RT_TUNE_SHADE_WAIT, 1), (capi.RT_TUNE_SHADOW_DONE_LANES, 64), (capi.RT_TUNE_REFILL_LANES, 1)),
+    ((capi.RT_TUNE_TILE_ORDER, 0),),   # tiles handed out in image order instead of most expensive first
 ])
 def test_scheduling_knobs_do_not_change_output(scenes, tuning):
     run_batched(scenes["boxes"], 96, 54, 3, 4, 2, tuning)
