@@ -146,6 +146,11 @@ RT_HD float luminance(f3 c) { return dot(c, mk3(0.2126f, 0.7152f, 0.0722f)); }
 // nodes4     8 x f4 per 4-wide node (persistent kernel): lo.x[4] lo.y[4] lo.z[4]
 //            hi.x[4] hi.y[4] hi.z[4] links[4] pad; same link encoding; unused
 //            slots (2 and 3 only) carry the link kNoRoot.
+// nodes4q    the same tree, same node numbers, in 4 x f4 = 64 bytes per node (persistent kernel, large scenes):
+//            the node's own box origin and a power-of-two step per axis, the four child boxes as 8-bit
+//            multiples of the steps from the origin (rounded outwards), the four links:
+//            (origin.xyz, step exponents) (lo.x[4] lo.y[4] lo.z[4] hi.x[4] as bytes) (hi.y[4] hi.z[4] as
+//            bytes, link0, link1) (link2, link3, 0, 0); see lane_visit4q in rt_lane.h
 // tri_isect  3 x f4 per triangle in leaf order:
 //            (v0.xyz, e01.x) (e01.yz, e02.xy) (e02.z, unit normal.xyz) -- the normal is
 //            tri_shade's, so that the back-face test needs no further fetch
@@ -167,6 +172,7 @@ RT_HD float luminance(f3 c) { return dot(c, mk3(0.2126f, 0.7152f, 0.0722f)); }
 struct SceneView {
     const f4 *nodes;
     const f4 *nodes4;
+    const f4 *nodes4q;
     const f4 *tri_isect;
     const f4 *tri_shade;
     const f4 *tri_shade_leaf;

@@ -98,7 +98,10 @@ __host__ __device__ inline int stripe_global_row(const StripeMap &m, int local)
 #define RT_TOUCH_TOP 1
 #endif
 #ifndef RT_LEAF_LOOP
-#define RT_LEAF_LOOP 0 // 1: a triangle step tests every triangle of the leaf, not only the next one
+#define RT_LEAF_LOOP 0 // small scenes; 1: a triangle step tests every triangle of the leaf, not only the next one
+#endif
+#ifndef RT_LARGE_LEAF_LOOP
+#define RT_LARGE_LEAF_LOOP 1 // the same for large scenes, whose leaves are fuller
 #endif
 #ifndef RT_LDS_PARK
 #define RT_LDS_PARK 2
@@ -122,8 +125,9 @@ __host__ __device__ inline int stripe_global_row(const StripeMap &m, int local)
 #define RT_PARK2_MINW 6
 #endif
 
-template <int BLOCK, class Entry, int CAP = 1 << 30, bool SPILL = false>
+template <int BLOCK, class Entry, int CAP = 1 << 30, bool SPILL = false, bool QUANT = false>
 struct LdsStack {
+    static constexpr bool kQuantNodes = QUANT; // the links on this stack count 64-byte nodes (rt::lane_visit4q)
     Entry *base;
     int sp;
     // SPILL: entries CAP and above live in global memory, entry j of a lane at spill[(j - CAP) * spill_stride]
@@ -164,6 +168,7 @@ struct LdsStack {
 //          builder also writes them when they fit 16 bits (BuiltScene::links_packed), instead of from
 //          its link vector: six loads per node visit instead of seven (-1.4 % on suzanne, -2.1 % on
 //          boxes; the same with 24-bit links for large scenes measured no gain).  Follows LINK16.
+//          64: the lanes visit the 64-byte nodes (8-bit child boxes relative to the node's own; large scenes).
 template <int STACK_, int PARK_, int MINW_, bool LINK16_, bool SPILL_, int PLANE_LINKS_ = (LINK16_ && RT_PACKED_LINKS) ? 16 : 0>
 struct LaneCfg {
     static constexpr int STACK = STACK_, PARK = PARK_, MINW = MINW_, PLANE_LINKS = PLANE_LINKS_;
@@ -403,7 +408,7 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
     __shared__ StackEntry lds_stack[STACK * kBlock];
     __shared__ float lds_park[PARK > 0 ? PARK * kBlock : 1];
     const int lane = threadIdx.x & 63;
-    LdsStack<kBlock, StackEntry, STACK, CFG::SPILL> stack;
+    LdsStack<kBlock, StackEntry, STACK, CFG::SPILL, CFG::PLANE_LINKS == 64> stack;
     stack.base = lds_stack + threadIdx.x;
     stack.sp = 0;
     stack.spill = CFG::SPILL ? spill + ((size_t)blockIdx.x * kBlock + threadIdx.x) : nullptr;
@@ -682,18 +687,19 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
             bool any_inner = __ballot(L.mode == rt::kLaneTraverse && rt::link_is_inner(L.cur)) != 0ull;
             if (n_leaf != 0 && (n_leaf >= sched.leaf_lanes || !any_inner)) {
                 if (COUNT) { ph_leaf_it++; ph_leaf_ln += n_leaf; tc0 = clock64(); }
-#if RT_LEAF_LOOP
-                // all triangles of the leaf in one go (lanes with fewer triangles idle in the later rounds)
-                int rounds = leaf ? (int)((uint32_t)~L.cur & 7u) + 1 : 0;
-                while (__ballot(rounds > 0) != 0ull) {
-                    if (rounds > 0) {
-                        rt::lane_step_triangle(sc, L, stack, cp);
-                        rounds = L.mode == rt::kLaneTraverse ? rounds - 1 : 0;
+                if (CFG::LINK16 ? RT_LEAF_LOOP : RT_LARGE_LEAF_LOOP) {
+                    // All triangles of the leaf in one go (lanes with fewer triangles idle in the later rounds).  Pays
+                    // where leaves are full: a lane's ray waits one memory round trip per turn, and the later
+                    // triangles of a leaf lie in the cache lines its first one brought in (+14 % on 991k triangles,
+                    // +3 % on the 131k-triangle height field; suzanne's 581 leaves hold 982 triangles and lose 0.5 %).
+                    int rounds = leaf ? (int)((uint32_t)~L.cur & 7u) + 1 : 0;
+                    while (__ballot(rounds > 0) != 0ull) {
+                        if (rounds > 0) {
+                            rt::lane_step_triangle(sc, L, stack, cp);
+                            rounds = L.mode == rt::kLaneTraverse ? rounds - 1 : 0;
+                        }
                     }
-                }
-#else
-                if (leaf) rt::lane_step_triangle(sc, L, stack, cp);
-#endif
+                } else if (leaf) rt::lane_step_triangle(sc, L, stack, cp);
                 if (COUNT) tc_tri += clock64() - tc0;
             }
 
@@ -910,6 +916,7 @@ struct rt_context {
     rt::SceneView view{};
     uint32_t *d_tri_orig = nullptr;
     rt::f4 *d_tri_shade_leaf = nullptr;
+    rt::f4 *d_nodes4q = nullptr;
     rt::f4 *d_nodes = nullptr, *d_nodes4 = nullptr, *d_tri_isect = nullptr, *d_tri_shade = nullptr, *d_tri_raw = nullptr, *d_spheres = nullptr,
            *d_lights = nullptr;
     bool has_scene = false;
@@ -974,10 +981,10 @@ struct rt_context {
 
     void free_scene()
     {
-        for (rt::f4 *p : {d_nodes, d_nodes4, d_tri_isect, d_tri_shade, d_tri_shade_leaf, d_tri_raw, d_spheres, d_lights}) (void)hipFree(p);
+        for (rt::f4 *p : {d_nodes4q, d_nodes, d_nodes4, d_tri_isect, d_tri_shade, d_tri_shade_leaf, d_tri_raw, d_spheres, d_lights}) (void)hipFree(p);
         (void)hipFree(d_tri_orig);
         d_tri_orig = nullptr;
-        d_nodes = d_nodes4 = d_tri_isect = d_tri_shade = d_tri_shade_leaf = d_tri_raw = d_spheres = d_lights = nullptr;
+        d_nodes4q = d_nodes = d_nodes4 = d_tri_isect = d_tri_shade = d_tri_shade_leaf = d_tri_raw = d_spheres = d_lights = nullptr;
         has_scene = false;
     }
 };
@@ -1044,7 +1051,7 @@ template <class CFG, bool COUNT, bool FUSED>
 int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchParams &bp, unsigned int *counter, hipStream_t stream)
 {
     auto kernel = render_persistent_kernel<CFG, COUNT, FUSED>;
-    if (CFG::PLANE_LINKS != 0 && c->host_scene.links_packed != CFG::PLANE_LINKS)
+    if (CFG::PLANE_LINKS == 16 && c->host_scene.links_packed != CFG::PLANE_LINKS)
         return fail(RT_ERR_UNSUPPORTED, "internal: kernel variant and node link packing do not match");
     int per_cu = c->tune_blocks_per_cu;
     if (per_cu <= 0) {
@@ -1112,8 +1119,17 @@ uint32_t persistent_stack_need(const rt_context *c)
 
 using CfgSmall = LaneCfg<RT_PARK2_STACK, RT_PARK2_SLOTS, RT_PARK2_MINW, true, false>;
 using CfgSmallDeep = LaneCfg<32, 14, RT_MINW, true, false>;
-using CfgLarge = LaneCfg<RT_LARGE_STACK, RT_LARGE_SLOTS, RT_LARGE_MINW, false, false>;
-using CfgLargeDeep = LaneCfg<RT_LARGE_STACK, RT_LARGE_SLOTS, RT_LARGE_MINW, false, true>;
+#ifndef RT_LARGE_NODES
+// Node form of the large-scene kernels: 0 = the 128-byte nodes, 64 = the 64-byte ones (8-bit child boxes relative to
+// the node's own).  Measured with 64: four loads per visit instead of seven and half the node bytes, but 35 more
+// VALU instructions per visit, and a plane can sit a whole step (1/255 of the parent's extent) further out: the
+// floor and the walls, thin leaves directly under the root, then contain the origin of every ray that leaves them and
+// are tested once more per ray (+0.5 to +1.7 triangle tests per ray).  991k triangles 11.9 -> 12.8 ms/frame, the
+// unseen mesh 10.0 -> 12.0, the 131k-triangle height field 15.9 -> 17.9: not used.
+#define RT_LARGE_NODES 0
+#endif
+using CfgLarge = LaneCfg<RT_LARGE_STACK, RT_LARGE_SLOTS, RT_LARGE_MINW, false, false, RT_LARGE_NODES>;
+using CfgLargeDeep = LaneCfg<RT_LARGE_STACK, RT_LARGE_SLOTS, RT_LARGE_MINW, false, true, RT_LARGE_NODES>;
 using CfgRegisters = LaneCfg<64, 0, 2, false, false>; // 64 KB of LDS per block: two blocks per CU
 
 // Scenes whose links fit 16 bits: node indices below 32768 and leaf codes (first << 3 | count - 1) below 32768.
@@ -1478,13 +1494,14 @@ static int upload_scene(rt_context *c, const void *spheres, uint32_t n_spheres, 
     opt.max_leaf = (uint32_t)c->tune_max_leaf;
     opt.triangle_cost = 0.1f * (float)c->tune_tri_cost_x10;
     opt.origin_mag = origin_mag;
+    opt.quant_nodes = RT_LARGE_NODES == 64;
     rt::build_scene(spheres, n_spheres, triangles, n_triangles, opt, c->host_scene);
     if (c->host_scene.max_depth >= 64) return fail(RT_ERR_UNSUPPORTED, "acceleration structure too deep");
     // the 4-wide node step addresses nodes by a 32-bit byte offset
     if (c->host_scene.nodes4.size() * sizeof(rt::f4) >= (1ull << 32)) return fail(RT_ERR_UNSUPPORTED, "too many nodes");
     const rt::BuiltScene &hs = c->host_scene;
     int rc;
-    if ((rc = upload(hs.nodes, &c->d_nodes, c->stream)) || (rc = upload(hs.nodes4, &c->d_nodes4, c->stream)) || (rc = upload(hs.tri_isect, &c->d_tri_isect, c->stream)) ||
+    if ((rc = upload(hs.nodes, &c->d_nodes, c->stream)) || (rc = upload(hs.nodes4, &c->d_nodes4, c->stream)) || (rc = upload(hs.nodes4q, &c->d_nodes4q, c->stream)) || (rc = upload(hs.tri_isect, &c->d_tri_isect, c->stream)) ||
         (rc = upload(hs.tri_shade, &c->d_tri_shade, c->stream)) || (rc = upload(hs.tri_shade_leaf, &c->d_tri_shade_leaf, c->stream)) ||
         (rc = upload(hs.tri_orig, &c->d_tri_orig, c->stream)) || (rc = upload(hs.tri_raw, &c->d_tri_raw, c->stream)) ||
         (rc = upload(hs.spheres, &c->d_spheres, c->stream)) || (rc = upload(hs.lights, &c->d_lights, c->stream))) {
@@ -1492,9 +1509,9 @@ static int upload_scene(rt_context *c, const void *spheres, uint32_t n_spheres, 
         return rc;
     }
     RT_HIP_CHECK(hipStreamSynchronize(c->stream));
-    c->scene_bytes = (hs.nodes.size() + hs.nodes4.size() + hs.tri_isect.size() + hs.tri_shade.size() + hs.tri_shade_leaf.size() + hs.tri_orig.size() / 4 + hs.spheres.size() + hs.lights.size()) * sizeof(rt::f4);
+    c->scene_bytes = (hs.nodes.size() + hs.nodes4.size() + hs.nodes4q.size() + hs.tri_isect.size() + hs.tri_shade.size() + hs.tri_shade_leaf.size() + hs.tri_orig.size() / 4 + hs.spheres.size() + hs.lights.size()) * sizeof(rt::f4);
     rt::SceneView &v = c->view;
-    v.nodes = c->d_nodes; v.nodes4 = c->d_nodes4; v.root4 = hs.root4; v.tri_isect = c->d_tri_isect; v.tri_shade = c->d_tri_shade; v.tri_shade_leaf = c->d_tri_shade_leaf; v.tri_orig = c->d_tri_orig; v.tri_raw = c->d_tri_raw;
+    v.nodes = c->d_nodes; v.nodes4 = c->d_nodes4; v.nodes4q = c->d_nodes4q; v.root4 = hs.root4; v.tri_isect = c->d_tri_isect; v.tri_shade = c->d_tri_shade; v.tri_shade_leaf = c->d_tri_shade_leaf; v.tri_orig = c->d_tri_orig; v.tri_raw = c->d_tri_raw;
     v.spheres = c->d_spheres; v.lights = c->d_lights;
     v.n_spheres = hs.n_spheres; v.n_tris = hs.n_tris; v.n_lights = hs.n_lights; v.n_lights_pass1 = hs.n_lights_pass1;
     v.total_power = hs.total_power; v.root = hs.root;

@@ -140,11 +140,18 @@ struct stack_touches_top : std::false_type {};
 template <class T>
 struct stack_touches_top<T, std::void_t<decltype(T::kTouchesTop)>> : std::integral_constant<bool, T::kTouchesTop> {};
 
-// Address of the record a link points at: a 4-wide node or the first triangle of a leaf.
+// Whether a stack type says that the lanes traverse the 64-byte nodes (Stack::kQuantNodes).
+template <class T, class = void>
+struct stack_quant_nodes : std::false_type {};
+template <class T>
+struct stack_quant_nodes<T, std::void_t<decltype(T::kQuantNodes)>> : std::integral_constant<bool, T::kQuantNodes> {};
+
+// Address of the record a link points at: a 4-wide node (128- or 64-byte form) or the first triangle of a leaf.
+template <bool QUANT>
 RT_HD const char *link_address(const SceneView &sc, int32_t link)
 {
-    return link >= 0 ? (const char *)sc.nodes4 + ((size_t)link << 7)
-                     : (const char *)(sc.tri_isect + kTriRecord * (size_t)((uint32_t)~link >> 3));
+    if (link < 0) return (const char *)(sc.tri_isect + kTriRecord * (size_t)((uint32_t)~link >> 3));
+    return QUANT ? (const char *)sc.nodes4q + ((size_t)link << 6) : (const char *)sc.nodes4 + ((size_t)link << 7);
 }
 
 template <class Stack>
@@ -330,11 +337,54 @@ RT_HD void lane_visit4(const char *node, uint32_t at, Lane &L, Stack &stack, Tes
     lane_descend4<PACKED>(L, stack, tn, h, lk, cnt);
 }
 
-// One visit of the 4-wide node L.cur.
+// Byte i of u as a float (one v_cvt_f32_ubyte instruction each).
+RT_HD void bytes4(uint32_t u, float out[4])
+{
+    out[0] = (float)(u & 0xffu); out[1] = (float)((u >> 8) & 0xffu);
+    out[2] = (float)((u >> 16) & 0xffu); out[3] = (float)(u >> 24);
+}
+
+// One visit of a 4-wide node in its 64-byte form (SceneView::nodes4q): a child plane is origin + q * step with
+// an 8-bit q, so its slab distance (origin + q * step) * inv + ood is one FMA on q: q * (step * inv) +
+// (origin * inv + ood), the two constants made once per axis and visit.  Four loads (three of 16 bytes, one of
+// 8) instead of seven, half the bytes; the boxes are the 128-byte form's moved outwards by less than a step
+// (1/255 of the node's extent), and the folded arithmetic moves a distance by a few 1e-7 of the magnitudes
+// involved, which the padding of the triangle boxes covers like the rounding of the unfolded form.
+template <class Stack>
+RT_HD void lane_visit4q(const char *node, Lane &L, Stack &stack, TestCounts *cnt)
+{
+    f4 h0 = read_whole((const f4 *)node), h1 = read_whole((const f4 *)(node + 16)), h2 = read_whole((const f4 *)(node + 32));
+    float l2 = *(const float *)(node + 48), l3 = *(const float *)(node + 52);
+    uint32_t ex = f2u(h0.w);
+    float sx = u2f((ex & 0xffu) << 23), sy = u2f(((ex >> 8) & 0xffu) << 23), sz = u2f(((ex >> 16) & 0xffu) << 23);
+    float ax = sx * L.rb.inv.x, ay = sy * L.rb.inv.y, az = sz * L.rb.inv.z;
+    float bx = __builtin_fmaf(h0.x, L.rb.inv.x, L.rb.ood.x), by = __builtin_fmaf(h0.y, L.rb.inv.y, L.rb.ood.y),
+          bz = __builtin_fmaf(h0.z, L.rb.inv.z, L.rb.ood.z);
+    // the plane entered first is the low one for a non-negative direction, the high one otherwise
+    bool nx = (int32_t)f2u(L.rb.inv.x) < 0, ny = (int32_t)f2u(L.rb.inv.y) < 0, nz = (int32_t)f2u(L.rb.inv.z) < 0;
+    uint32_t lox = f2u(h1.x), loy = f2u(h1.y), loz = f2u(h1.z), hix = f2u(h1.w), hiy = f2u(h2.x), hiz = f2u(h2.y);
+    float qnx[4], qny[4], qnz[4], qfx[4], qfy[4], qfz[4];
+    bytes4(nx ? hix : lox, qnx); bytes4(nx ? lox : hix, qfx);
+    bytes4(ny ? hiy : loy, qny); bytes4(ny ? loy : hiy, qfy);
+    bytes4(nz ? hiz : loz, qnz); bytes4(nz ? loz : hiz, qfz);
+    float tn[4];
+    bool h[4];
+    for (int i = 0; i < 4; i++) {
+        float nearx = __builtin_fmaf(qnx[i], ax, bx), neary = __builtin_fmaf(qny[i], ay, by), nearz = __builtin_fmaf(qnz[i], az, bz);
+        float farx = __builtin_fmaf(qfx[i], ax, bx), fary = __builtin_fmaf(qfy[i], ay, by), farz = __builtin_fmaf(qfz[i], az, bz);
+        tn[i] = fmaxf(fmaxf(nearx, neary), fmaxf(nearz, 0.0f));
+        float tf = fminf(fminf(farx, fary), fminf(farz, L.tmax));
+        h[i] = tn[i] <= tf;
+    }
+    lane_descend4<0>(L, stack, tn, h, mk4(h2.z, h2.w, l2, l3), cnt);
+}
+
+// One visit of the 4-wide node L.cur.  PACKED 64 selects the 64-byte nodes.
 template <int PACKED = 0, class Stack>
 RT_HD void lane_step_inner4(const SceneView &sc, Lane &L, Stack &stack, TestCounts *cnt)
 {
-    lane_visit4<PACKED>((const char *)sc.nodes4, (uint32_t)L.cur << 7, L, stack, cnt);
+    if (PACKED == 64) lane_visit4q((const char *)sc.nodes4q + ((size_t)(uint32_t)L.cur << 6), L, stack, cnt);
+    else lane_visit4<PACKED>((const char *)sc.nodes4, (uint32_t)L.cur << 7, L, stack, cnt);
 }
 
 // The node visit of whichever tree the lanes traverse.
@@ -367,7 +417,7 @@ RT_HD void lane_step_triangle(const SceneView &sc, Lane &L, Stack &stack, TestCo
     float touched = 0.0f;
     if constexpr (stack_touches_top<Stack>::value) {
         // what the lane visits after this leaf is known already: start bringing it into the caches
-        if (left == 0u && stack.top_in_lds()) touched = *(const float *)link_address(sc, stack.top());
+        if (left == 0u && stack.top_in_lds()) touched = *(const float *)link_address<stack_quant_nodes<Stack>::value>(sc, stack.top());
     }
     float t = triangle_t(L.o, L.d, xyz(a), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x));
     if (cnt) cnt->tris++;

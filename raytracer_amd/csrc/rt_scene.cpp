@@ -6,6 +6,7 @@
 #include "rt_scene.h"
 
 #include <algorithm>
+#include <cmath>
 #include <array>
 #include <functional>
 #include <cstring>
@@ -457,8 +458,33 @@ void build_scene(const void *spheres, uint32_t n_spheres, const void *triangles,
         uint32_t need_g = collapse(true, wide_g, wide_of_g);
         if (need_g <= opt.prefer_stack) { wide.swap(wide_g); wide_of.swap(wide_of_g); out.max_stack4 = need_g; }
     }
+    // Node numbers: the inner children of a node get consecutive numbers, subtrees follow depth-first, so
+    // that siblings share cache lines (two 64-byte nodes per line) and a subtree is a contiguous range.
+    std::vector<int32_t> number_of(wide.size(), -1), at_number;
+    at_number.reserve(wide.size());
+    {
+        std::vector<int32_t> todo{0};
+        number_of[0] = 0;
+        at_number.push_back(0);
+        while (!todo.empty()) {
+            int32_t wi = todo.back();
+            todo.pop_back();
+            const Wide &w = wide[wi];
+            size_t first = todo.size();
+            for (int k = 0; k < w.n; k++)
+                if (bn[w.child[k]].child[0] >= 0) {
+                    int32_t ci = wide_of[w.child[k]];
+                    number_of[ci] = (int32_t)at_number.size();
+                    at_number.push_back(ci);
+                    todo.push_back(ci);
+                }
+            std::reverse(todo.begin() + first, todo.end()); // the first child's subtree comes first
+        }
+    }
     out.nodes4.assign(wide.size() * 8, mk4(0, 0, 0, 0));
-    for (size_t wi = 0; wi < wide.size(); wi++) {
+    if (opt.quant_nodes) out.nodes4q.assign(wide.size() * 4, mk4(0, 0, 0, 0));
+    for (size_t number = 0; number < wide.size(); number++) {
+        const size_t wi = (size_t)at_number[number];
         const Wide &w = wide[wi];
         float v[6][4];
         uint32_t link[4];
@@ -467,15 +493,48 @@ void build_scene(const void *spheres, uint32_t n_spheres, const void *triangles,
                 const Box &cb = bn[w.child[k]].box;
                 for (int a = 0; a < 3; a++) { v[a][k] = cb.lo[a]; v[3 + a][k] = cb.hi[a]; }
                 int32_t c = w.child[k];
-                link[k] = (uint32_t)(bn[c].child[0] >= 0 ? wide_of[c] : leaf_link(bn[c].first, bn[c].count));
+                link[k] = (uint32_t)(bn[c].child[0] >= 0 ? number_of[wide_of[c]] : leaf_link(bn[c].first, bn[c].count));
             } else {
                 for (int a = 0; a < 3; a++) { v[a][k] = 0.0f; v[3 + a][k] = 0.0f; }
                 link[k] = (uint32_t)kNoRoot;
             }
         }
-        f4 *n = &out.nodes4[8 * wi];
+        f4 *n = &out.nodes4[8 * number];
         for (int r = 0; r < 6; r++) n[r] = mk4(v[r][0], v[r][1], v[r][2], v[r][3]);
         n[6] = mk4(u2f(link[0]), u2f(link[1]), u2f(link[2]), u2f(link[3]));
+
+        if (!opt.quant_nodes) continue;
+        // The 64-byte form.  Per axis: origin = the low plane of the node's own box, step = the smallest power
+        // of two with 255 steps covering the box; a child plane is origin + q * step with q rounded outwards
+        // (checked in double precision, which holds origin + q * step exactly).
+        const Box &own = bn[w.bin_node].box;
+        uint32_t expo[3], q[6] = {0, 0, 0, 0, 0, 0}; // q[r]: plane r of the four children, one byte each
+        for (int a = 0; a < 3; a++) {
+            double origin = own.lo[a], extent = (double)own.hi[a] - origin;
+            int e = -100;
+            if (extent > 0.0) e = std::max(-100, (int)std::ceil(std::log2(extent / 255.0)));
+            for (;; e++) { // until every child plane fits 0..255
+                double step = std::ldexp(1.0, e);
+                bool fits = true;
+                uint32_t lo_q = 0, hi_q = 0;
+                for (int k = 0; k < w.n && fits; k++) {
+                    double ql = std::floor((v[a][k] - origin) / step), qh = std::ceil((v[3 + a][k] - origin) / step);
+                    while (origin + ql * step > v[a][k]) ql -= 1.0;
+                    while (origin + qh * step < v[3 + a][k]) qh += 1.0;
+                    ql = std::max(ql, 0.0); // the child lies inside the node's own box: plane 0 is its low side
+                    if (qh > 255.0) { fits = false; break; }
+                    lo_q |= (uint32_t)ql << (8 * k);
+                    hi_q |= (uint32_t)qh << (8 * k);
+                }
+                if (fits) { q[a] = lo_q; q[3 + a] = hi_q; break; }
+            }
+            expo[a] = (uint32_t)(e + 127); // the exponent field of the float 2^e
+        }
+        f4 *nq = &out.nodes4q[4 * number];
+        nq[0] = mk4(own.lo[0], own.lo[1], own.lo[2], u2f(expo[0] | (expo[1] << 8) | (expo[2] << 16)));
+        nq[1] = mk4(u2f(q[0]), u2f(q[1]), u2f(q[2]), u2f(q[3]));
+        nq[2] = mk4(u2f(q[4]), u2f(q[5]), u2f(link[0]), u2f(link[1]));
+        nq[3] = mk4(u2f(link[2]), u2f(link[3]), 0.0f, 0.0f);
     }
     out.root4 = 0;
     out.links_packed = 0;

@@ -10,7 +10,7 @@ if levels < 0:
     hf = heightfield_scene(-levels)
     cam, sp, tr = hf.camera, S.pack_spheres(hf.spheres), S.pack_triangles(hf.triangles)
 else:
-    cam, sp, tr = subdivided_suzanne_packed(levels)
+    cam, sp, tr = subdivided_suzanne_packed(levels, float(sys.argv[3])) if len(sys.argv) > 3 else subdivided_suzanne_packed(levels)
 ctx = capi.Context(W, H)
 ctx.set_max_bounces(8)
 for k, name_ in enumerate(['SHADE', 'LEAF', 'BPC', 'BATCH', 'SDONE', 'REFILL']):

@@ -3,6 +3,7 @@
 // against the oracle in a container without a GPU.  Test infrastructure only:
 // the shipped library has no CPU rendering path.
 #include <atomic>
+#include <cmath>
 #include <cstdlib>
 #include <climits>
 #include <cstring>
@@ -74,9 +75,46 @@ extern "C" int har_check_link_packing(const void *spheres, uint32_t n_spheres, c
     return bad;
 }
 
+// Checks the 64-byte nodes against the 128-byte ones of the same scene: same links, and every child plane,
+// decoded exactly (origin + q * 2^e in double precision), lies outwards of (or on) the 128-byte node's plane by
+// less than one step.  Returns the number of violations.
+extern "C" int har_check_quant_nodes(const void *spheres, uint32_t n_spheres, const void *tris, uint32_t n_tris)
+{
+    rt::BuiltScene b;
+    rt::BuildOptions opt;
+    opt.pack_links = false;
+    opt.quant_nodes = true;
+    rt::build_scene(spheres, n_spheres, tris, n_tris, opt, b);
+    if (b.nodes4q.size() * 2 != b.nodes4.size()) return 1 << 30;
+    int bad = 0;
+    for (size_t n = 0; n < b.nodes4.size() / 8; n++) {
+        const float *full = &b.nodes4[8 * n].x;
+        const rt::f4 *q = &b.nodes4q[4 * n];
+        uint32_t ex = rt::f2u(q[0].w);
+        const float origin[3] = {q[0].x, q[0].y, q[0].z};
+        const uint32_t planes[6] = {rt::f2u(q[1].x), rt::f2u(q[1].y), rt::f2u(q[1].z), rt::f2u(q[1].w), rt::f2u(q[2].x), rt::f2u(q[2].y)};
+        const uint32_t links[4] = {rt::f2u(q[2].z), rt::f2u(q[2].w), rt::f2u(q[3].x), rt::f2u(q[3].y)};
+        for (int k = 0; k < 4; k++) {
+            uint32_t lf;
+            std::memcpy(&lf, full + 24 + k, 4);
+            if (lf != links[k]) bad++;
+            if ((int32_t)lf == rt::kNoRoot) continue;
+            for (int r = 0; r < 6; r++) {
+                int a = r % 3;
+                int e = (int)((ex >> (8 * a)) & 0xffu) - 127;
+                double step = std::ldexp(1.0, e), plane = (double)origin[a] + (double)((planes[r] >> (8 * k)) & 0xffu) * step;
+                double want = full[4 * r + k];
+                if (r < 3 ? (plane > want || plane < want - step) : (plane < want || plane > want + step)) bad++;
+            }
+        }
+    }
+    return bad;
+}
+
 // How the lane emulation reads a node's child links: 0 = from the link vector; -1 = as the kernels do
 // for the scene at hand (16-bit links packed into the low bytes of the node planes when the builder
-// says they fit, otherwise the link vector).
+// says they fit, otherwise the link vector); 64 = every scene through the 64-byte nodes (the kernels use them
+// for scenes whose links do not fit 16 bits).
 extern "C" void har_set_link_mode(int mode) { g_link_mode = mode; }
 
 extern "C" int har_render_frame(const void *uniforms80, const void *spheres, uint32_t n_spheres,
@@ -93,7 +131,7 @@ extern "C" int har_render_frame(const void *uniforms80, const void *spheres, uin
     if (!rt::make_frame_params(uniforms80, max_bounces, fp, err)) return -1;
     fp.sphere_lights = g_sphere_lights ? 1u : 0u;
     rt::SceneView sc{};
-    sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data(); sc.tri_shade_leaf = bs.tri_shade_leaf.data(); sc.tri_orig = bs.tri_orig.data();
+    sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.nodes4q = bs.nodes4q.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data(); sc.tri_shade_leaf = bs.tri_shade_leaf.data(); sc.tri_orig = bs.tri_orig.data();
     sc.tri_raw = bs.tri_raw.data(); sc.spheres = bs.spheres.data(); sc.lights = bs.lights.data();
     sc.n_spheres = bs.n_spheres; sc.n_tris = bs.n_tris; sc.n_lights = bs.n_lights;
     sc.n_lights_pass1 = bs.n_lights_pass1; sc.total_power = bs.total_power; sc.root = bs.root;
@@ -153,7 +191,7 @@ extern "C" int har_debug_pixel(const void *uniforms80, const void *spheres, uint
     std::string err;
     if (!rt::make_frame_params(uniforms80, max_bounces, fp, err)) return -1;
     rt::SceneView sc{};
-    sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data(); sc.tri_shade_leaf = bs.tri_shade_leaf.data(); sc.tri_orig = bs.tri_orig.data();
+    sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.nodes4q = bs.nodes4q.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data(); sc.tri_shade_leaf = bs.tri_shade_leaf.data(); sc.tri_orig = bs.tri_orig.data();
     sc.tri_raw = bs.tri_raw.data(); sc.spheres = bs.spheres.data(); sc.lights = bs.lights.data();
     sc.n_spheres = bs.n_spheres; sc.n_tris = bs.n_tris; sc.n_lights = bs.n_lights;
     sc.n_lights_pass1 = bs.n_lights_pass1; sc.total_power = bs.total_power; sc.root = bs.root;
@@ -218,6 +256,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
     rt::BuiltScene bs;
     rt::BuildOptions opt;
     if (getenv("RT_GREEDY_COLLAPSE")) opt.greedy_collapse = true; // for tests/harness/tree_stats.py
+    opt.quant_nodes = g_link_mode == 64;
     rt::build_scene(spheres, n_spheres, tris, n_tris, opt, bs);
     float uni[20];
     std::memcpy(uni, uniforms80, 80);
@@ -226,7 +265,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
     std::string err;
     if (!rt::make_frame_params(uni, max_bounces, fp, err)) return -1;
     rt::SceneView sc{};
-    sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data(); sc.tri_shade_leaf = bs.tri_shade_leaf.data(); sc.tri_orig = bs.tri_orig.data();
+    sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.nodes4q = bs.nodes4q.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data(); sc.tri_shade_leaf = bs.tri_shade_leaf.data(); sc.tri_orig = bs.tri_orig.data();
     sc.tri_raw = bs.tri_raw.data(); sc.spheres = bs.spheres.data(); sc.lights = bs.lights.data();
     sc.n_spheres = bs.n_spheres; sc.n_tris = bs.n_tris; sc.n_lights = bs.n_lights;
     sc.n_lights_pass1 = bs.n_lights_pass1; sc.total_power = bs.total_power; sc.root = bs.root;
@@ -291,6 +330,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
                     if (L[i].mode == rt::kLaneTraverse && rt::link_is_inner(L[i].cur)) {
                         if (L[i].cur >= n_nodes4) { bad_links++; L[i].cur = rt::kNoRoot; L[i].mode = rt::kLaneShadeClosest; continue; }
                         if (link_mode == 16) rt::lane_step_node<16>(sc, L[i], st[i], &cnt);
+                        else if (requested_mode == 64) rt::lane_step_node<64>(sc, L[i], st[i], &cnt);
                         else rt::lane_step_node(sc, L[i], st[i], &cnt);
                     }
                 int n_leaf = 0, n_inner = 0;

@@ -10,7 +10,8 @@ if name.startswith("hf"):      # hf256: height field of 256 x 256 quads
     packed = (S.pack_spheres(sc.spheres), S.pack_triangles(sc.triangles))
 elif name.startswith("sub"):   # sub5: suzanne with its model split 5 times
     from tests.synth import subdivided_suzanne_packed
-    cam, sp, tr = subdivided_suzanne_packed(int(name[3:]))
+    lv, _, scale = name[3:].partition("x")   # sub5x32: the same with every coordinate scaled x32
+    cam, sp, tr = subdivided_suzanne_packed(int(lv), float(scale)) if scale else subdivided_suzanne_packed(int(lv))
     sc = S.Scene(camera=cam)
     packed = (sp, tr)
 else:

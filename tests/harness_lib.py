@@ -58,12 +58,13 @@ class HarnessRenderer:
         assert rc == 0
 
 
-    def render_frames_lanes(self, spp, first_frame, n_frames, shade_num=3, leaf_lanes=8, packed_links=False):
+    def render_frames_lanes(self, spp, first_frame, n_frames, shade_num=3, leaf_lanes=8, packed_links=False, quant_nodes=False):
         """The persistent kernel's per-lane state machine, 64 lanes per emulated wave.  packed_links:
         child links are read as the kernels read them for this scene (from the low bytes of the node
         planes when the builder packed them there); returns the link width used (0 or 16)."""
         u = self.S.pack_uniforms(self.scene.camera, first_frame, self.width, self.height, spp)
-        self.L.har_set_link_mode(-1 if packed_links else 0)
+        # quant_nodes: the lanes visit the 64-byte nodes (the kernels' node form for scenes of more than 4096 triangles)
+        self.L.har_set_link_mode(64 if quant_nodes else -1 if packed_links else 0)
         rc = self.L.har_render_frames_lanes(_p(u), _p(self.spheres), len(self.spheres), _p(self.tris), len(self.tris),
                                             self.max_bounces, first_frame, n_frames, shade_num, leaf_lanes,
                                             _p(self.accum), _p(self.frame_f16), _p(self.ids), _p(self.counters),

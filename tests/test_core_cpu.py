@@ -149,6 +149,41 @@ def test_links_packed_into_the_node_planes(scenes, which, expect):
     assert int(har.counters[0]) == int(orc.counters[0])
 
 
+@pytest.mark.parametrize("which", ["suzanne", "boxes", "card_deck", "heightfield", "rotated_camera", "shuffled_duplicates"])
+def test_lanes_over_the_64_byte_nodes_match_oracle(scenes, which):
+    """The large-scene kernels visit 64-byte nodes: child boxes as 8-bit multiples of a power-of-two step from
+    the node's own box, rounded outwards.  Boxes only decide what is visited: the emulated lanes over those
+    nodes must give the oracle's image bit for bit on any scene."""
+    from tests.synth import card_deck_scene, edge_scenes, heightfield_scene
+
+    scene = {"card_deck": lambda: card_deck_scene(3000), "heightfield": lambda: heightfield_scene(48),
+             "rotated_camera": lambda: edge_scenes()["rotated_camera"],
+             "shuffled_duplicates": lambda: edge_scenes()["shuffled_duplicates"]}.get(which, lambda: scenes[which])()
+    orc = O.OracleRenderer(scene, 40, 23)
+    orc.set_samples_per_pixel(2)
+    orc.render_frames(2)
+    har = HarnessRenderer(scene, 40, 23)
+    har.render_frames_lanes(2, 1, 2, quant_nodes=True)
+    assert np.array_equal(har.ids, orc.ids)
+    assert np.array_equal(har.frame_f16, orc.frame_f16)
+    assert np.array_equal(har.accum, orc.accum)
+    assert int(har.counters[0]) == int(orc.counters[0])
+
+
+def test_64_byte_nodes_enclose_the_128_byte_ones(scenes):
+    from raytracer_amd import scene as S
+    from tests.harness_lib import lib
+    from tests.synth import heightfield_scene
+    import ctypes as C
+
+    L = lib()
+    L.har_check_quant_nodes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    L.har_check_quant_nodes.restype = C.c_int
+    for scene in (scenes["suzanne"], scenes["boxes"], heightfield_scene(64)):
+        sp, tr = S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles)
+        assert L.har_check_quant_nodes(sp.ctypes.data_as(C.c_void_p), len(sp), tr.ctypes.data_as(C.c_void_p), len(tr)) == 0
+
+
 def test_link_packing_only_moves_planes_outwards(scenes):
     """Property check of the builder's link packing against an unpacked build of the same scene: planes
     move outwards by at most 512 ulp, the bytes spell the links, the z planes and the link vector are
