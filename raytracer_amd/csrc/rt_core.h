@@ -570,14 +570,14 @@ RT_HD LightSample sample_light_spheres(const SceneView &sc, f3 hit_point, uint32
     out.direction = mk3(0, 0, 0); out.emission = mk3(0, 0, 0); out.distance = 0.0f; out.pdf = 0.0f;
     uint32_t light_count = 0u;
     for (uint32_t i = 0; i < sc.n_spheres; i++)
-        if (sc.spheres[4 * i + 2].w > 0.0f) light_count++;
+        if (read_uniform(sc.spheres + 4 * i + 2).w > 0.0f) light_count++;
     if (light_count == 0u) return out;
 
     uint32_t random_sphere_index = (uint32_t)(rand_f(state) * (float)light_count);
     uint32_t current_index = 0u;
     f4 s0 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
     for (uint32_t i = 0; i < sc.n_spheres; i++) {
-        if (sc.spheres[4 * i + 2].w > 0.0f) {
+        if (read_uniform(sc.spheres + 4 * i + 2).w > 0.0f) {
             if (current_index == random_sphere_index) { s0 = sc.spheres[4 * i]; s2 = sc.spheres[4 * i + 2]; break; }
             current_index++;
         }

@@ -169,26 +169,36 @@ struct LdsStack {
 //          its link vector: six loads per node visit instead of seven (-1.4 % on suzanne, -2.1 % on
 //          boxes; the same with 24-bit links for large scenes measured no gain).  Follows LINK16.
 //          64: the lanes visit the 64-byte nodes (8-bit child boxes relative to the node's own; large scenes).
-template <int STACK_, int PARK_, int MINW_, bool LINK16_, bool SPILL_, int PLANE_LINKS_ = (LINK16_ && RT_PACKED_LINKS) ? 16 : 0>
+//   SL     the sphere-light extension (rt::lane_shade_closest<true>): seven more parked dwords per lane, in LDS
+template <int STACK_, int PARK_, int MINW_, bool LINK16_, bool SPILL_, int PLANE_LINKS_ = (LINK16_ && RT_PACKED_LINKS) ? 16 : 0, bool SL_ = false>
 struct LaneCfg {
     static constexpr int STACK = STACK_, PARK = PARK_, MINW = MINW_, PLANE_LINKS = PLANE_LINKS_;
-    static constexpr bool LINK16 = LINK16_, SPILL = SPILL_;
+    static constexpr bool LINK16 = LINK16_, SPILL = SPILL_, SL = SL_;
+    static constexpr int PARK_LDS = PARK_ + (SL_ ? rt::kParkSecondShadowFloats : 0); // floats per lane in LDS
 };
 constexpr int kSpillEntries = 64 - RT_LARGE_STACK; // trees whose traversal needs up to 64 entries
 
 // rt::RegPark's interface with the first NLDS slots in LDS (slot k of lane l at
 // base[k * BLOCK + l]) and the rest in registers.  Slot numbers are compile-time constants at
 // every use, so each access resolves to one or the other.
-template <int BLOCK, int NLDS>
+// SECOND: the slots of the sphere-light extension's second shadow ray (rt::kParkS2D ...) are in LDS too, after
+// the first NLDS.
+template <int BLOCK, int NLDS, bool SECOND = false>
 struct LdsPark {
     float *base;
     float regs[NLDS < rt::kParkFloats ? rt::kParkFloats - NLDS : 1];
+    // position in LDS of a slot, -1 if it lives in a register
+    static __device__ constexpr int lds_index(int slot)
+    {
+        return slot < NLDS ? slot
+                           : (SECOND && slot >= rt::kParkS2D && slot < rt::kParkS2D + rt::kParkSecondShadowFloats) ? NLDS + slot - rt::kParkS2D : -1;
+    }
     __device__ void put(int slot, float x)
     {
-        if (slot < NLDS) base[slot * BLOCK] = x;
+        if (lds_index(slot) >= 0) base[lds_index(slot) * BLOCK] = x;
         else regs[slot - NLDS] = x;
     }
-    __device__ float get(int slot) const { return slot < NLDS ? base[slot * BLOCK] : regs[slot - NLDS]; }
+    __device__ float get(int slot) const { return lds_index(slot) >= 0 ? base[lds_index(slot) * BLOCK] : regs[slot - NLDS]; }
 };
 
 // ---------------------------------------------------------------------------
@@ -367,7 +377,7 @@ template <class CFG>
 struct LaneColumn {
     using Entry = typename std::conditional<CFG::LINK16, int16_t, int32_t>::type;
     static constexpr int kParkRegs = CFG::PARK < rt::kParkFloats ? rt::kParkFloats - CFG::PARK : 0;
-    static constexpr int kDwords = CFG::PARK + CFG::STACK * (int)sizeof(Entry) / 4;
+    static constexpr int kDwords = CFG::PARK_LDS + CFG::STACK * (int)sizeof(Entry) / 4;
     static constexpr int kImage = 19 + kParkRegs;                      // dwords of register state per path
     static constexpr int kColumnsPerImage = (kImage + kDwords - 1) / kDwords;
     static constexpr int kMaxDonate = 64 / (1 + kColumnsPerImage);     // live lanes a donor can have: each needs that many dead ones
@@ -375,15 +385,15 @@ struct LaneColumn {
 
     __device__ static uint32_t load(const Entry *st, const float *pk, int col, int i)
     {
-        if (i < CFG::PARK) return rt::f2u(pk[i * kBlock + col]);
-        int j = i - CFG::PARK;
+        if (i < CFG::PARK_LDS) return rt::f2u(pk[i * kBlock + col]);
+        int j = i - CFG::PARK_LDS;
         if (sizeof(Entry) == 4) return (uint32_t)st[j * kBlock + col];
         return (uint32_t)(uint16_t)st[(2 * j) * kBlock + col] | ((uint32_t)(uint16_t)st[(2 * j + 1) * kBlock + col] << 16);
     }
     __device__ static void store(Entry *st, float *pk, int col, int i, uint32_t v)
     {
-        if (i < CFG::PARK) { pk[i * kBlock + col] = rt::u2f(v); return; }
-        int j = i - CFG::PARK;
+        if (i < CFG::PARK_LDS) { pk[i * kBlock + col] = rt::u2f(v); return; }
+        int j = i - CFG::PARK_LDS;
         if (sizeof(Entry) == 4) { st[j * kBlock + col] = (Entry)v; return; }
         st[(2 * j) * kBlock + col] = (Entry)(v & 0xffffu);
         st[(2 * j + 1) * kBlock + col] = (Entry)(v >> 16);
@@ -406,14 +416,14 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
     constexpr int STACK = CFG::STACK, PARK = CFG::PARK;
     using StackEntry = typename std::conditional<CFG::LINK16, int16_t, int32_t>::type;
     __shared__ StackEntry lds_stack[STACK * kBlock];
-    __shared__ float lds_park[PARK > 0 ? PARK * kBlock : 1];
+    __shared__ float lds_park[CFG::PARK_LDS > 0 ? CFG::PARK_LDS * kBlock : 1];
     const int lane = threadIdx.x & 63;
     LdsStack<kBlock, StackEntry, STACK, CFG::SPILL, CFG::PLANE_LINKS == 64> stack;
     stack.base = lds_stack + threadIdx.x;
     stack.sp = 0;
     stack.spill = CFG::SPILL ? spill + ((size_t)blockIdx.x * kBlock + threadIdx.x) : nullptr;
     stack.spill_stride = gridDim.x * kBlock;
-    LdsPark<kBlock, PARK> park;
+    LdsPark<kBlock, PARK, CFG::SL> park;
     park.base = lds_park + threadIdx.x;
 #if RT_MIGRATE
     using Column = LaneColumn<CFG>;
@@ -708,7 +718,7 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
             n_sdone = __popcll(__ballot(sdone));
             if (n_sdone != 0 && (n_sdone >= sched.sdone_lanes || __ballot(L.mode == rt::kLaneTraverse) == 0ull)) {
                 if (COUNT) { ph_sdone_it++; ph_sdone_ln += n_sdone; tc0 = clock64(); }
-                if (sdone) rt::lane_shadow_done(sc, fp, L, stack, park, n_rays, cp);
+                if (sdone) rt::lane_shadow_done<CFG::SL>(sc, fp, L, stack, park, n_rays, cp);
                 if (COUNT) tc_sdone += clock64() - tc0;
             }
         }
@@ -716,7 +726,7 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
         // ---- shade the lanes whose closest-hit ray is finished ------------------------------------
         if (COUNT) { int n_sh = __popcll(__ballot(L.mode == rt::kLaneShadeClosest)); if (n_sh) { ph_shade_it++; ph_shade_ln += n_sh; } }
         if (COUNT) tc0 = clock64();
-        if (L.mode == rt::kLaneShadeClosest) rt::lane_shade_closest(sc, fp, L, stack, park, n_rays, cp);
+        if (L.mode == rt::kLaneShadeClosest) rt::lane_shade_closest<CFG::SL>(sc, fp, L, stack, park, n_rays, cp);
         if (COUNT) tc_shade += clock64() - tc0;
     }
     if (COUNT) tc_total = clock64() - tc_begin;
@@ -1131,6 +1141,8 @@ using CfgSmallDeep = LaneCfg<32, 14, RT_MINW, true, false>;
 using CfgLarge = LaneCfg<RT_LARGE_STACK, RT_LARGE_SLOTS, RT_LARGE_MINW, false, false, RT_LARGE_NODES>;
 using CfgLargeDeep = LaneCfg<RT_LARGE_STACK, RT_LARGE_SLOTS, RT_LARGE_MINW, false, true, RT_LARGE_NODES>;
 using CfgRegisters = LaneCfg<64, 0, 2, false, false>; // 64 KB of LDS per block: two blocks per CU
+// the sphere-light extension on small scenes: 22 x 2 + (14 + 7) x 4 = 128 bytes per lane, five blocks per CU
+using CfgSmallSL = LaneCfg<RT_PARK2_STACK, 14, 5, true, false, RT_PACKED_LINKS ? 16 : 0, true>;
 
 // Scenes whose links fit 16 bits: node indices below 32768 and leaf codes (first << 3 | count - 1) below 32768.
 bool scene_is_small(const rt_context *c)
@@ -1138,6 +1150,13 @@ bool scene_is_small(const rt_context *c)
     const rt::BuiltScene &hs = c->host_scene;
     return hs.n_tris <= 4096 && hs.nodes.size() / 4 < 32768 && hs.nodes4.size() / 8 < 32768 && persistent_stack_need(c) <= 32 &&
            (hs.links_packed == 16 || !RT_PACKED_LINKS);
+}
+
+// The sphere-light extension runs on the persistent kernel for scenes of 16-bit links whose tree fits the stack of
+// its instantiation; other scenes with the extension on go to the one-thread-per-pixel kernel.
+bool sphere_lights_on_persistent(const rt_context *c)
+{
+    return rt::kWideBvh && scene_is_small(c) && persistent_stack_need(c) <= (uint32_t)CfgSmallSL::STACK;
 }
 
 // Whether the persistent kernel renders the current scene with the instantiation that keeps the deep end of
@@ -1187,8 +1206,12 @@ int launch_persistent_d(rt_context *c, const rt::FrameParams &fp, const BatchPar
     // entries the traversal stack must hold
     uint32_t depth = persistent_stack_need(c);
     if (depth > kMaxStackEntries) return fail(RT_ERR_UNSUPPORTED, "acceleration structure too deep for the traversal stack");
-    if (c->tune_lds_state == 0 || !rt::kWideBvh) return launch_persistent_t<CfgRegisters, COUNT, FUSED>(c, fp, bp, counter, stream);
+    if ((c->tune_lds_state == 0 && !c->sphere_lights) || !rt::kWideBvh) return launch_persistent_t<CfgRegisters, COUNT, FUSED>(c, fp, bp, counter, stream);
     bool small = scene_is_small(c);
+    if (c->sphere_lights) {
+        if (!sphere_lights_on_persistent(c)) return fail(RT_ERR_UNSUPPORTED, "internal: sphere lights on a scene the persistent kernel does not take");
+        return launch_persistent_t<CfgSmallSL, COUNT, FUSED>(c, fp, bp, counter, stream);
+    }
     if (small) {
         if (depth <= (uint32_t)CfgSmall::STACK && c->tune_lds_state >= 2) return launch_persistent_t<CfgSmall, COUNT, FUSED>(c, fp, bp, counter, stream);
         return launch_persistent_t<CfgSmallDeep, COUNT, FUSED>(c, fp, bp, counter, stream);
@@ -1347,7 +1370,7 @@ static int render_frames_impl(rt_context *c, uint32_t first_frame_index, uint32_
 // its lanes count (4096; the reference's own limit is 16, src/webgpu-renderer.ts:233).
 static bool persistent_path(const rt_context *c)
 {
-    return c->mode == RT_MODE_BVH && !c->sphere_lights && !debug_view_active(c) &&
+    return c->mode == RT_MODE_BVH && (!c->sphere_lights || sphere_lights_on_persistent(c)) && !debug_view_active(c) &&
            persistent_stack_need(c) <= (uint32_t)c->tune_max_stack && c->uniforms[16] <= (float)rt::kMaxLaneSamples;
 }
 

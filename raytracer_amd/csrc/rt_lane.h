@@ -58,7 +58,7 @@ struct Lane {
     // pixel / frame
     uint32_t unit;        // (frame, pixel) unit number handed out by the scheduler
     uint32_t rng;
-    uint32_t bits;        // sample (bits 0-11), bounce (12-19), flags (20-23), cost so far (24-31), see below
+    uint32_t bits;        // sample (bits 0-11), bounce (12-19), flags (20-24), cost so far (25-31), see below
     // path
     f3 color, light;
     // ray in flight
@@ -79,9 +79,13 @@ struct Lane {
 //    closest hit (every sample of a frame starts on the same ray, raytracer_compute.wgsl:329-336,
 //    so it is traced once) and the sum of the samples' radiance.
 // RegPark keeps everything in registers.
+//  - with the sphere-light extension, the second shadow ray of a bounce while the first one flies (slots
+//    22-28): its direction, its limit distance and its pending addition to `light` (its origin is the first
+//    one's).
 enum {
     kParkNextO = 0, kParkNextD = 3, kParkNee = 6, kParkEm = 9, kParkNextT = 12, kParkNextId = 13, kParkShadowFloats = 14,
-    kParkTotal = 14, kParkPrimT = 17, kParkPrimId = 18, kParkPrimD = 19, kParkFloats = 22
+    kParkTotal = 14, kParkPrimT = 17, kParkPrimId = 18, kParkPrimD = 19,
+    kParkS2D = 22, kParkS2Limit = 25, kParkS2Nee = 26, kParkSecondShadowFloats = 7, kParkFloats = 29
 };
 
 struct RegPark {
@@ -111,9 +115,10 @@ constexpr uint32_t kBitSpec = 1u << 20;     // is_specular_bounce of the path
 constexpr uint32_t kBitAnyhit = 1u << 21;   // the ray in flight is a shadow ray
 constexpr uint32_t kBitHasEm = 1u << 22;    // L.em is to be added to light
 constexpr uint32_t kBitContinue = 1u << 23; // the path goes on after the shadow ray
-// Bits 24-31: the bounces of the pixel-frame's finished samples, added up and saturating at 255: what the
+constexpr uint32_t kBitShadow2 = 1u << 24;  // a second shadow ray of this bounce (sphere-light extension) is set aside
+// Bits 25-31: the bounces of the pixel-frame's finished samples, added up and saturating at 127: what the
 // unit has cost so far (two rays per bounce), for the scheduler (lane_unit_cost).
-constexpr uint32_t kCostShift = 24, kCostMask = 0xffu << kCostShift;
+constexpr uint32_t kCostShift = 25, kCostMask = 0x7fu << kCostShift;
 
 RT_HD uint32_t lane_sample(const Lane &L) { return L.bits & kSampleMask; }
 RT_HD uint32_t lane_bounce(const Lane &L) { return (L.bits >> kBounceShift) & 0xffu; }
@@ -458,7 +463,7 @@ RT_HD void lane_end_path(const FrameParams &fp, Lane &L, Park &park, RayCounts &
     f3 total = add(park_get3(park, kParkTotal), L.light);
     uint32_t sample = lane_sample(L) + 1u;
     uint32_t cost = lane_unit_cost(L) + lane_bounce(L);
-    cost = (cost > 255u ? 255u : cost) << kCostShift;
+    cost = (cost > 127u ? 127u : cost) << kCostShift;
     if (sample < fp.spp && (int32_t)f2u(park.get(kParkPrimId)) == kNoHit) {
         // The camera ray missed everything, and every remaining sample starts on that same ray: each
         // is ray_all -> miss -> light = 0.4 * color with color = 1 (raytracer_compute.wgsl:198-202),
@@ -520,7 +525,10 @@ RT_HD void lane_empty_pixel(Lane &L, Park &park)
 }
 
 // Lane in kLaneShadeClosest: consumes the closest-hit result.
-template <class Stack, class Park>
+// SL: the opt-in sphere-light extension (FrameParams::sphere_lights, rt_pixel.h): after the triangle-light
+// sample the emissive spheres are sampled too, which can give the bounce a second shadow ray; it is set
+// aside while the first one is traced.
+template <bool SL = false, class Stack, class Park>
 RT_HD void lane_shade_closest(const SceneView &sc, const FrameParams &fp, Lane &L, Stack &stack, Park &park,
                               RayCounts &n_rays, TestCounts *cnt)
 {
@@ -541,12 +549,24 @@ RT_HD void lane_shade_closest(const SceneView &sc, const FrameParams &fp, Lane &
         Hit hit = fetch_hit<true>(sc, L.o, L.d, id, t);
         f3 hit_point = add(L.o, scale(L.d, hit.t));
         LightSample ts = sample_light_triangles(sc, hit_point, L.rng);
-        bool shadow = false;
+        bool shadow = false, shadow2 = false;
         if (ts.pdf > 0.0f) {
             float cos_theta = dot(hit.normal, ts.direction);
             if (cos_theta > 0.0f) {
                 park_put3(park, kParkNee, nee_contribution(ts, hit.normal, cos_theta, L.color));
                 shadow = true;
+            }
+        }
+        LightSample ss;
+        if (SL) { // raytracer_compute.wgsl:226, wired like :211-225
+            ss = sample_light_spheres(sc, hit_point, L.rng);
+            if (ss.pdf > 0.0f) {
+                float cos_theta = dot(hit.normal, ss.direction);
+                if (cos_theta > 0.0f) {
+                    // the only shadow ray of the bounce takes the first one's place; otherwise it waits its turn
+                    park_put3(park, shadow ? kParkS2Nee : kParkNee, nee_contribution(ss, hit.normal, cos_theta, L.color));
+                    shadow2 = true;
+                }
             }
         }
         f3 no = L.o, nd = L.d, em;
@@ -555,8 +575,8 @@ RT_HD void lane_shade_closest(const SceneView &sc, const FrameParams &fp, Lane &
         bounce++;
         bool cont = alive && bounce < fp.max_bounces;
         L.bits = (L.bits & (kSampleMask | kCostMask)) | (bounce << kBounceShift) | (spec ? kBitSpec : 0u) | (has_em ? kBitHasEm : 0u) |
-                 (cont ? kBitContinue : 0u);
-        if (shadow) {
+                 (cont ? kBitContinue : 0u) | (SL && shadow && shadow2 ? kBitShadow2 : 0u);
+        if (shadow || (SL && shadow2)) {
             park_put3(park, kParkNextO, no);
             park_put3(park, kParkNextD, nd);
             park_put3(park, kParkEm, em);
@@ -572,6 +592,15 @@ RT_HD void lane_shade_closest(const SceneView &sc, const FrameParams &fp, Lane &
             launch = true;
             launch_anyhit = true;
             launch_limit = ts.distance - 0.1f;
+            if (SL && shadow2) {
+                if (shadow) {
+                    park_put3(park, kParkS2D, ss.direction);
+                    park.put(kParkS2Limit, ss.distance - 0.1f);
+                } else {
+                    L.d = ss.direction;
+                    launch_limit = ss.distance - 0.1f;
+                }
+            }
         } else {
             if (has_em) L.light = add(L.light, em);
             if (cont) { L.o = no; L.d = nd; launch = true; }
@@ -583,11 +612,19 @@ RT_HD void lane_shade_closest(const SceneView &sc, const FrameParams &fp, Lane &
 }
 
 // Lane in kLaneShadowDone: consumes the shadow result (raytracer_compute.wgsl:219-224, :242).
-template <class Stack, class Park>
+template <bool SL = false, class Stack, class Park>
 RT_HD void lane_shadow_done(const SceneView &sc, const FrameParams &fp, Lane &L, Stack &stack, Park &park,
                             RayCounts &n_rays, TestCounts *cnt)
 {
     if (L.best_id == kNoHit) L.light = add(L.light, park_get3(park, kParkNee));
+    if (SL && lane_flag(L, kBitShadow2)) {
+        // the bounce's second shadow ray, from the same origin (L.o is untouched by the traversal)
+        lane_set_flag(L, kBitShadow2, false);
+        L.d = park_get3(park, kParkS2D);
+        park_put3(park, kParkNee, park_get3(park, kParkS2Nee));
+        lane_launch_ray(sc, L, stack, true, park.get(kParkS2Limit), n_rays, cnt);
+        return;
+    }
     if (lane_flag(L, kBitHasEm)) L.light = add(L.light, park_get3(park, kParkEm));
     if (lane_flag(L, kBitContinue)) {
         L.o = park_get3(park, kParkNextO);

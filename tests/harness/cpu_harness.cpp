@@ -270,6 +270,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
     sc.n_spheres = bs.n_spheres; sc.n_tris = bs.n_tris; sc.n_lights = bs.n_lights;
     sc.n_lights_pass1 = bs.n_lights_pass1; sc.total_power = bs.total_power; sc.root = bs.root;
 
+    const bool sl = g_sphere_lights != 0; // the sphere-light extension, as set by har_set_sphere_lights
     const int requested_mode = g_link_mode;
     const int link_mode = requested_mode < 0 ? bs.links_packed : 0;
     g_link_mode = link_mode; // what HostStack sees during this call
@@ -346,11 +347,21 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
                             rt::lane_step_triangle(sc, L[i], st[i], &cnt);
                         }
                 for (int i = 0; i < 64; i++)
-                    if (L[i].mode == rt::kLaneShadowDone) rt::lane_shadow_done(sc, fp, L[i], st[i], park[i], n_rays, &cnt);
+                    if (L[i].mode == rt::kLaneShadowDone) {
+                        if (sl) rt::lane_shadow_done<true>(sc, fp, L[i], st[i], park[i], n_rays, &cnt);
+                        else rt::lane_shadow_done(sc, fp, L[i], st[i], park[i], n_rays, &cnt);
+                    }
             }
             for (int i = 0; i < 64; i++) {
-                if (L[i].mode == rt::kLaneShadowDone) rt::lane_shadow_done(sc, fp, L[i], st[i], park[i], n_rays, &cnt);
-                if (L[i].mode == rt::kLaneShadeClosest) rt::lane_shade_closest(sc, fp, L[i], st[i], park[i], n_rays, &cnt);
+                // (a shadow hand-over can start the bounce's second shadow ray, which a lane may finish at once)
+                while (L[i].mode == rt::kLaneShadowDone) {
+                    if (sl) rt::lane_shadow_done<true>(sc, fp, L[i], st[i], park[i], n_rays, &cnt);
+                    else rt::lane_shadow_done(sc, fp, L[i], st[i], park[i], n_rays, &cnt);
+                }
+                if (L[i].mode == rt::kLaneShadeClosest) {
+                    if (sl) rt::lane_shade_closest<true>(sc, fp, L[i], st[i], park[i], n_rays, &cnt);
+                    else rt::lane_shade_closest(sc, fp, L[i], st[i], park[i], n_rays, &cnt);
+                }
             }
             for (int i = 0; i < 64; i++) {
                 if (L[i].mode != rt::kLanePixelDone) continue;

@@ -65,6 +65,7 @@ class HarnessRenderer:
         u = self.S.pack_uniforms(self.scene.camera, first_frame, self.width, self.height, spp)
         # quant_nodes: the lanes visit the 64-byte nodes (the kernels' node form for scenes of more than 4096 triangles)
         self.L.har_set_link_mode(64 if quant_nodes else -1 if packed_links else 0)
+        self.L.har_set_sphere_lights(1 if self.sphere_lights else 0)
         rc = self.L.har_render_frames_lanes(_p(u), _p(self.spheres), len(self.spheres), _p(self.tris), len(self.tris),
                                             self.max_bounces, first_frame, n_frames, shade_num, leaf_lanes,
                                             _p(self.accum), _p(self.frame_f16), _p(self.ids), _p(self.counters),

@@ -170,6 +170,25 @@ def test_lanes_over_the_64_byte_nodes_match_oracle(scenes, which):
     assert int(har.counters[0]) == int(orc.counters[0])
 
 
+def test_sphere_light_extension_in_the_lane_state_machine():
+    """The same extension through the per-lane state machine of the persistent kernel: a bounce can have two
+    shadow rays, the second one set aside while the first is traced; the additions to `light` stay in the
+    shader's order."""
+    from tests.synth import edge_scenes
+
+    for name in ("emissive_and_mirror_spheres", "many_spheres", "no_lights"):
+        scene = edge_scenes()[name]
+        orc = O.OracleRenderer(scene, 64, 36, sphere_lights=True)
+        orc.set_samples_per_pixel(3)
+        orc.render_frames(2)
+        har = HarnessRenderer(scene, 64, 36, sphere_lights=True)
+        har.render_frames_lanes(3, 1, 2)
+        assert np.array_equal(har.ids, orc.ids)
+        assert np.array_equal(har.frame_f16, orc.frame_f16)
+        assert np.array_equal(har.accum, orc.accum)
+        assert int(har.counters[0]) == int(orc.counters[0])
+
+
 def test_64_byte_nodes_enclose_the_128_byte_ones(scenes):
     from raytracer_amd import scene as S
     from tests.harness_lib import lib

@@ -430,6 +430,11 @@ def test_sphere_light_extension(mode):
         assert _f16_equal(ctx.read_frame_f16(), orc.frame_f16)
         assert np.array_equal(ctx.read_accum(), orc.accum_rgb())
         assert int(ctx.read_counters()[0]) == int(orc.counters[0])
+        if mode == capi.RT_MODE_BVH:
+            # these scenes are rendered by the persistent kernel (its instrumented build counts node-step rounds)
+            ctx.set_counting(True)
+            ctx.render_frames(4, 1)
+            assert int(ctx.read_counters()[5]) > 0
         ctx.close()
 
 
