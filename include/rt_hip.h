@@ -74,7 +74,10 @@ typedef enum rt_tuning {
     RT_TUNE_TILE_ORDER = 14,   /* 1 (default): a launch hands out first the 8x8 tiles whose longest pixel took the most
                                   rays in the previous launch, so that what is started last is short (frames of 4 samples per pixel or more);
                                   0 = image order */
-    RT_TUNE_END = 15           /* one past the last key */
+    RT_TUNE_LINEAR_SPHERES = 15, /* scenes of up to this many spheres test every sphere per ray, as the reference does;
+                                  scenes of more keep their spheres in the acceleration structure (default 8); takes
+                                  effect at the next rt_set_scene */
+    RT_TUNE_END = 16           /* one past the last key */
 } rt_tuning;
 
 /* Message of the last failure on the calling thread ("" if none). */

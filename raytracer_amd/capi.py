@@ -23,6 +23,7 @@ RT_TUNE_MAX_STACK = 11
 RT_TUNE_COALESCE_FRAMES = 12
 RT_TUNE_MIGRATE_LANES = 13
 RT_TUNE_TILE_ORDER = 14
+RT_TUNE_LINEAR_SPHERES = 15
 RT_TUNE_MAX_LEAF, RT_TUNE_TRI_COST_X10, RT_TUNE_LDS_STATE, RT_TUNE_OVERLAP_FRAMES, RT_TUNE_SHADE_WAIT = 6, 7, 8, 9, 10
 
 # name -> (restype, argtypes); must list every symbol include/rt_hip.h declares

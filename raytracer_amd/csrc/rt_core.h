@@ -164,6 +164,9 @@ RT_HD float luminance(f3 c) { return dot(c, mk3(0.2126f, 0.7152f, 0.0722f)); }
 // tri_shade_leaf  the same records in leaf order
 // tri_raw    the reference's 96-byte records (brute-force mode only)
 // spheres    the reference's 64-byte records = 4 x f4
+// sph_leaf   scenes of many spheres (BuildOptions::linear_spheres): the spheres are leaves of the tree too.  A leaf
+//            holds triangles or spheres, never both; leaf positions n_tris and up stand for spheres, position
+//            n_tris + k for sph_leaf[k] = (centre, radius) of the sphere with original index sph_orig[k]
 // lights     5 x f4 per emissive triangle in original order, plus one trailing
 //            all-zero "nothing selected" entry:
 //            (v0.xyz, area) (v1.xyz, power/total_power) (v2.xyz, running power sum)
@@ -179,7 +182,10 @@ struct SceneView {
     const uint32_t *tri_orig;
     const f4 *tri_raw;
     const f4 *spheres;
+    const f4 *sph_leaf;        // (centre, radius) of the spheres that are leaves of the tree, in leaf order
+    const uint32_t *sph_orig;  // their original indices
     const f4 *lights;
+    uint32_t n_linear_spheres; // spheres every ray tests one by one: n_spheres, or 0 when they are in the tree
     uint32_t n_spheres;
     uint32_t n_tris;
     uint32_t n_lights;       // entries with emissionStrength > 0
@@ -305,6 +311,9 @@ RT_HD bool slab(const RayBox &rb, float lox, float loy, float loz, float hix, fl
 
 RT_HD bool all_nan(f3 d) { return (d.x != d.x) && (d.y != d.y) && (d.z != d.z); }
 
+// Whether leaf position `first` stands for a sphere (SceneView::sph_leaf).
+RT_HD bool leaf_holds_spheres(const SceneView &sc, uint32_t first) { return first >= sc.n_tris; }
+
 // Closest hit with the reference's selection rule (raytracer_compute.wgsl:15-39):
 // among hits with t > 0 the smallest t wins, ties go to the lowest index in
 // ray_all order (spheres first).  Returns the id, -1 on a miss.
@@ -317,7 +326,7 @@ RT_HD int32_t trace_closest(const SceneView &sc, f3 ro, f3 rd, Stack &stack, flo
     // reference (all comparisons false, t = NaN is not > 0): a miss.
     if (all_nan(rd)) { out_t = -1.0f; return -1; }
 
-    for (uint32_t i = 0; i < sc.n_spheres; i++) {
+    for (uint32_t i = 0; i < sc.n_linear_spheres; i++) {
         float tn;
         float t = sphere_t(ro, rd, sc.spheres[4 * i], tn);
         if (cnt) cnt->spheres++;
@@ -349,6 +358,14 @@ RT_HD int32_t trace_closest(const SceneView &sc, f3 ro, f3 rd, Stack &stack, flo
                 uint32_t code = (uint32_t)~cur;
                 uint32_t first = code >> 3, count = (code & 7u) + 1u;
                 for (uint32_t k = 0; k < count; k++) {
+                    if (leaf_holds_spheres(sc, first)) {
+                        float tn;
+                        float t = sphere_t(ro, rd, sc.sph_leaf[first + k - sc.n_tris], tn);
+                        int32_t id = (int32_t)sc.sph_orig[first + k - sc.n_tris];
+                        if (cnt) cnt->spheres++;
+                        if (t > 0.0f && (t < best_t || (t == best_t && id < best_id))) { best_t = t; best_id = id; }
+                        continue;
+                    }
                     const f4 *tr = sc.tri_isect + kTriRecord * (size_t)(first + k);
                     f4 a = tr[0], b = tr[1], c = tr[2];
                     float t = triangle_t(ro, rd, xyz(a), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x));
@@ -379,7 +396,7 @@ template <class Stack>
 RT_HD bool trace_occluded(const SceneView &sc, f3 ro, f3 rd, float limit, Stack &stack, TestCounts *cnt)
 {
     if (all_nan(rd)) return false;
-    for (uint32_t i = 0; i < sc.n_spheres; i++) {
+    for (uint32_t i = 0; i < sc.n_linear_spheres; i++) {
         float tn;
         float t = sphere_t(ro, rd, sc.spheres[4 * i], tn);
         if (cnt) cnt->spheres++;
@@ -406,6 +423,13 @@ RT_HD bool trace_occluded(const SceneView &sc, f3 ro, f3 rd, float limit, Stack 
             uint32_t code = (uint32_t)~cur;
             uint32_t first = code >> 3, count = (code & 7u) + 1u;
             for (uint32_t k = 0; k < count; k++) {
+                if (leaf_holds_spheres(sc, first)) {
+                    float tn;
+                    float t = sphere_t(ro, rd, sc.sph_leaf[first + k - sc.n_tris], tn);
+                    if (cnt) cnt->spheres++;
+                    if (t > 0.0f && !(t > limit)) return true;
+                    continue;
+                }
                 const f4 *tr = sc.tri_isect + kTriRecord * (size_t)(first + k);
                 f4 a = tr[0], b = tr[1], c = tr[2];
                 float t = triangle_t(ro, rd, xyz(a), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x));

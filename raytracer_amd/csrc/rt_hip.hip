@@ -926,7 +926,8 @@ struct rt_context {
     rt::SceneView view{};
     uint32_t *d_tri_orig = nullptr;
     rt::f4 *d_tri_shade_leaf = nullptr;
-    rt::f4 *d_nodes4q = nullptr;
+    rt::f4 *d_nodes4q = nullptr, *d_sph_leaf = nullptr;
+    uint32_t *d_sph_orig = nullptr;
     rt::f4 *d_nodes = nullptr, *d_nodes4 = nullptr, *d_tri_isect = nullptr, *d_tri_shade = nullptr, *d_tri_raw = nullptr, *d_spheres = nullptr,
            *d_lights = nullptr;
     bool has_scene = false;
@@ -963,6 +964,7 @@ struct rt_context {
     uint32_t *d_tile_order[1 + kMaxSlots] = {}, *d_tile_cls[1 + kMaxSlots] = {};
     int tile_cost_phase[1 + kMaxSlots] = {};
     int tune_tile_order = 1;
+    int tune_linear_spheres = 8;
     int next_slot = 0;
     // Submission coalescing of rt_render_frame (see flush_pending): frames pending_first ..
     // pending_first + pending_n - 1 have been asked for and not launched yet.
@@ -991,9 +993,11 @@ struct rt_context {
 
     void free_scene()
     {
-        for (rt::f4 *p : {d_nodes4q, d_nodes, d_nodes4, d_tri_isect, d_tri_shade, d_tri_shade_leaf, d_tri_raw, d_spheres, d_lights}) (void)hipFree(p);
+        for (rt::f4 *p : {d_sph_leaf, d_nodes4q, d_nodes, d_nodes4, d_tri_isect, d_tri_shade, d_tri_shade_leaf, d_tri_raw, d_spheres, d_lights}) (void)hipFree(p);
         (void)hipFree(d_tri_orig);
-        d_tri_orig = nullptr;
+        (void)hipFree(d_sph_orig);
+        d_tri_orig = d_sph_orig = nullptr;
+        d_sph_leaf = nullptr;
         d_nodes4q = d_nodes = d_nodes4 = d_tri_isect = d_tri_shade = d_tri_shade_leaf = d_tri_raw = d_spheres = d_lights = nullptr;
         has_scene = false;
     }
@@ -1148,7 +1152,7 @@ using CfgSmallSL = LaneCfg<RT_PARK2_STACK, 14, 5, true, false, RT_PACKED_LINKS ?
 bool scene_is_small(const rt_context *c)
 {
     const rt::BuiltScene &hs = c->host_scene;
-    return hs.n_tris <= 4096 && hs.nodes.size() / 4 < 32768 && hs.nodes4.size() / 8 < 32768 && persistent_stack_need(c) <= 32 &&
+    return hs.n_tris + hs.n_tree_spheres <= 4096 && hs.nodes.size() / 4 < 32768 && hs.nodes4.size() / 8 < 32768 && persistent_stack_need(c) <= 32 &&
            (hs.links_packed == 16 || !RT_PACKED_LINKS);
 }
 
@@ -1518,13 +1522,15 @@ static int upload_scene(rt_context *c, const void *spheres, uint32_t n_spheres, 
     opt.triangle_cost = 0.1f * (float)c->tune_tri_cost_x10;
     opt.origin_mag = origin_mag;
     opt.quant_nodes = RT_LARGE_NODES == 64;
+    opt.linear_spheres = (uint32_t)c->tune_linear_spheres;
     rt::build_scene(spheres, n_spheres, triangles, n_triangles, opt, c->host_scene);
     if (c->host_scene.max_depth >= 64) return fail(RT_ERR_UNSUPPORTED, "acceleration structure too deep");
     // the 4-wide node step addresses nodes by a 32-bit byte offset
     if (c->host_scene.nodes4.size() * sizeof(rt::f4) >= (1ull << 32)) return fail(RT_ERR_UNSUPPORTED, "too many nodes");
     const rt::BuiltScene &hs = c->host_scene;
     int rc;
-    if ((rc = upload(hs.nodes, &c->d_nodes, c->stream)) || (rc = upload(hs.nodes4, &c->d_nodes4, c->stream)) || (rc = upload(hs.nodes4q, &c->d_nodes4q, c->stream)) || (rc = upload(hs.tri_isect, &c->d_tri_isect, c->stream)) ||
+    if ((rc = upload(hs.nodes, &c->d_nodes, c->stream)) || (rc = upload(hs.nodes4, &c->d_nodes4, c->stream)) || (rc = upload(hs.nodes4q, &c->d_nodes4q, c->stream)) ||
+        (rc = upload(hs.sph_leaf, &c->d_sph_leaf, c->stream)) || (rc = upload(hs.sph_orig, &c->d_sph_orig, c->stream)) || (rc = upload(hs.tri_isect, &c->d_tri_isect, c->stream)) ||
         (rc = upload(hs.tri_shade, &c->d_tri_shade, c->stream)) || (rc = upload(hs.tri_shade_leaf, &c->d_tri_shade_leaf, c->stream)) ||
         (rc = upload(hs.tri_orig, &c->d_tri_orig, c->stream)) || (rc = upload(hs.tri_raw, &c->d_tri_raw, c->stream)) ||
         (rc = upload(hs.spheres, &c->d_spheres, c->stream)) || (rc = upload(hs.lights, &c->d_lights, c->stream))) {
@@ -1536,6 +1542,7 @@ static int upload_scene(rt_context *c, const void *spheres, uint32_t n_spheres, 
     rt::SceneView &v = c->view;
     v.nodes = c->d_nodes; v.nodes4 = c->d_nodes4; v.nodes4q = c->d_nodes4q; v.root4 = hs.root4; v.tri_isect = c->d_tri_isect; v.tri_shade = c->d_tri_shade; v.tri_shade_leaf = c->d_tri_shade_leaf; v.tri_orig = c->d_tri_orig; v.tri_raw = c->d_tri_raw;
     v.spheres = c->d_spheres; v.lights = c->d_lights;
+    v.sph_leaf = c->d_sph_leaf; v.sph_orig = c->d_sph_orig; v.n_linear_spheres = hs.n_spheres - hs.n_tree_spheres;
     v.n_spheres = hs.n_spheres; v.n_tris = hs.n_tris; v.n_lights = hs.n_lights; v.n_lights_pass1 = hs.n_lights_pass1;
     v.total_power = hs.total_power; v.root = hs.root;
     v.debug_view = 0u;
@@ -1660,6 +1667,7 @@ int rt_set_tuning(rt_context *c, int key, int value)
     case RT_TUNE_COALESCE_FRAMES: if (value < 0 || value > 256) return fail(RT_ERR_INVALID, "coalesce_frames out of range"); c->tune_coalesce = value; break;
     case RT_TUNE_MAX_STACK: if (value < 1 || value > (int)kMaxStackEntries) return fail(RT_ERR_INVALID, "max_stack out of range"); c->tune_max_stack = value; break;
     case RT_TUNE_SHADOW_DONE_LANES: if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "shadow_done_lanes out of range"); c->tune_sdone_lanes = value; break;
+    case RT_TUNE_LINEAR_SPHERES: if (value < 0) return fail(RT_ERR_INVALID, "linear_spheres out of range"); c->tune_linear_spheres = value; break;
     case RT_TUNE_TILE_ORDER: if (value < 0 || value > 1) return fail(RT_ERR_INVALID, "tile_order must be 0 or 1"); c->tune_tile_order = value; break;
     case RT_TUNE_MIGRATE_LANES: if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "migrate_lanes out of range"); c->tune_migrate = RT_MIGRATE ? value : 0; break;
     default: return fail(RT_ERR_INVALID, "unknown tuning key");

@@ -155,7 +155,11 @@ struct stack_quant_nodes<T, std::void_t<decltype(T::kQuantNodes)>> : std::integr
 template <bool QUANT>
 RT_HD const char *link_address(const SceneView &sc, int32_t link)
 {
-    if (link < 0) return (const char *)(sc.tri_isect + kTriRecord * (size_t)((uint32_t)~link >> 3));
+    if (link < 0) {
+        uint32_t first = (uint32_t)~link >> 3;
+        return leaf_holds_spheres(sc, first) ? (const char *)(sc.sph_leaf + (first - sc.n_tris))
+                                             : (const char *)(sc.tri_isect + kTriRecord * (size_t)first);
+    }
     return QUANT ? (const char *)sc.nodes4q + ((size_t)link << 6) : (const char *)sc.nodes4 + ((size_t)link << 7);
 }
 
@@ -170,7 +174,7 @@ RT_HD void lane_pop(Lane &L, Stack &stack)
 // merged into L.tmax / L.best_id under the reference's selection rule.
 RT_HD void lane_test_spheres(const SceneView &sc, Lane &L, TestCounts *cnt)
 {
-    for (uint32_t i = 0; i < sc.n_spheres; i++) {
+    for (uint32_t i = 0; i < sc.n_linear_spheres; i++) {
         f4 s0 = read_uniform(sc.spheres + 4 * i);
         float tn;
         float t = sphere_t(L.o, L.d, s0, tn);
@@ -213,7 +217,7 @@ RT_HD void spheres_closest(const SceneView &sc, f3 o, f3 d, float &best_t, int32
     best_t = INFINITY;
     best_id = kNoHit;
     if (all_nan(d)) return;
-    for (uint32_t i = 0; i < sc.n_spheres; i++) {
+    for (uint32_t i = 0; i < sc.n_linear_spheres; i++) {
         float tn;
         float t = sphere_t(o, d, read_uniform(sc.spheres + 4 * i), tn);
         if (cnt) cnt->spheres++;
@@ -417,6 +421,29 @@ RT_HD void lane_step_triangle(const SceneView &sc, Lane &L, Stack &stack, TestCo
 {
     uint32_t code = (uint32_t)~L.cur;
     uint32_t first = code >> 3, left = code & 7u; // triangles after this one
+    if (leaf_holds_spheres(sc, first)) {
+        // a sphere of a leaf of spheres: the sphere part of ray_all (raytracer_compute.wgsl:19-24) for this one,
+        // as lane_test_spheres does it for spheres outside the tree; ids are original indices, all below any
+        // triangle's, so on a tie in t the lower number wins whatever the other is
+        uint32_t k = first - sc.n_tris;
+        float tn;
+        float t = sphere_t(L.o, L.d, read_whole(sc.sph_leaf + k), tn);
+        int32_t id = (int32_t)sc.sph_orig[k];
+        if (cnt) cnt->spheres++;
+        bool occluder = false;
+        if (t > 0.0f) {
+            if (lane_flag(L, kBitAnyhit)) {
+                if (!(t > L.tmax)) { L.best_id = id; occluder = true; }
+            } else if (t < L.tmax || (t == L.tmax && id < L.best_id)) {
+                L.tmax = t;
+                L.best_id = id;
+            }
+        }
+        if (occluder) { L.cur = kNoRoot; L.mode = kLaneShadowDone; }
+        else if (left != 0u) L.cur = (int32_t)~(((first + 1u) << 3) | (left - 1u));
+        else lane_pop(L, stack);
+        return;
+    }
     const f4 *tr = sc.tri_isect + kTriRecord * (size_t)first;
     f4 a = read_whole(tr + 0), b = read_whole(tr + 1), c = read_whole(tr + 2); // three 16-byte loads, not 12 + 16 + 16 + 4
     float touched = 0.0f;

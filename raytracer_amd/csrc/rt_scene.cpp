@@ -74,7 +74,8 @@ Box padded_triangle_box(const float *rec, float origin_mag)
 
 class Builder {
 public:
-    Builder(std::vector<Prim> &prims, const BuildOptions &opt) : prims_(prims), opt_(opt) {}
+    // first_sphere: prims with an index from here on are spheres; a leaf holds one kind only
+    Builder(std::vector<Prim> &prims, const BuildOptions &opt, uint32_t first_sphere) : prims_(prims), opt_(opt), first_sphere_(first_sphere) {}
 
     int32_t build(uint32_t first, uint32_t count, uint32_t depth)
     {
@@ -105,8 +106,15 @@ public:
         bool split = false;
         if (!force_median) split = sah_split(first, count, node.box, cbox, mid);
         if (!split) {
-            if (count <= opt_.max_leaf) return self;
-            median_split(first, count, cbox, mid);
+            if (count <= opt_.max_leaf) {
+                // a leaf, unless it would hold triangles and spheres: then the two kinds part here
+                auto it = std::partition(prims_.begin() + first, prims_.begin() + first + count,
+                                         [&](const Prim &p) { return p.index < first_sphere_; });
+                mid = (uint32_t)(it - prims_.begin());
+                if (mid == first || mid == first + count) return self;
+            } else {
+                median_split(first, count, cbox, mid);
+            }
         }
         int32_t l = build(first, mid - first, depth + 1);
         int32_t r = build(mid, first + count - mid, depth + 1);
@@ -194,6 +202,7 @@ private:
 
     std::vector<Prim> &prims_;
     const BuildOptions &opt_;
+    uint32_t first_sphere_;
 };
 
 f3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
@@ -288,32 +297,71 @@ void build_scene(const void *spheres, uint32_t n_spheres, const void *triangles,
     out.coord_mag = coord_mag;
     out.origin_mag = std::max(opt.origin_mag, coord_mag);
 
-    // BVH over padded triangle boxes.
-    if (n_tris == 0) return;
-    std::vector<Prim> prims(n_tris);
+    // Spheres join the tree as leaves of their own kind when there are more than a ray can afford to test one by
+    // one (and their records are finite, so that their boxes are; leaf positions must leave bit 28 free).
+    bool tree_spheres = n_spheres > opt.linear_spheres && n_tris < (1u << 27);
+    for (uint32_t i = 0; i < n_spheres && tree_spheres; i++) {
+        const float *sp = (const float *)out.spheres.data() + (size_t)i * 16;
+        for (int a = 0; a < 4; a++)
+            if (!(std::fabs(sp[a]) < std::numeric_limits<float>::infinity())) tree_spheres = false;
+    }
+    out.n_tree_spheres = tree_spheres ? n_spheres : 0u;
+
+    // BVH over padded boxes of the triangles and of those spheres.
+    const uint32_t n_prims = n_tris + out.n_tree_spheres;
+    if (n_prims == 0) return;
+    std::vector<Prim> prims(n_prims);
     for (uint32_t i = 0; i < n_tris; i++) {
         const float *r = T + (size_t)i * 24;
         prims[i].box = padded_triangle_box(r, out.origin_mag);
         for (int a = 0; a < 3; a++) prims[i].centroid[a] = 0.5f * (prims[i].box.lo[a] + prims[i].box.hi[a]);
         prims[i].index = i;
     }
-    Builder b(prims, opt);
-    int32_t root = b.build(0, n_tris, 0);
+    for (uint32_t i = 0; i < out.n_tree_spheres; i++) {
+        // The sphere test accepts what its f32 discriminant accepts, a ray a few 1e-7 of the magnitudes outside
+        // the exact sphere included; the margin follows the triangles' (padded_triangle_box).
+        const float *sp = (const float *)out.spheres.data() + (size_t)i * 16;
+        float radius = std::fabs(sp[3]);
+        float mag = std::max(std::fabs(sp[0]), std::max(std::fabs(sp[1]), std::fabs(sp[2]))) + radius;
+        float pad = 2e-4f + 2e-3f * radius + 4e-6f * mag + 2e-6f * std::max(0.0f, out.origin_mag - kOriginMagCovered);
+        Prim &p = prims[n_tris + i];
+        for (int a = 0; a < 3; a++) { p.box.lo[a] = sp[a] - radius - pad; p.box.hi[a] = sp[a] + radius + pad; p.centroid[a] = sp[a]; }
+        p.index = n_tris + i;
+    }
+    Builder b(prims, opt, n_tris);
+    int32_t root = b.build(0, n_prims, 0);
     out.max_depth = b.max_depth;
+
+    // Leaf positions: the triangles count 0 .. n_tris - 1 in the order the builder left them in, the spheres
+    // n_tris .. after them; a leaf holds one kind, so its members are consecutive in either count.
+    std::vector<uint32_t> position(n_prims);
+    {
+        uint32_t t = 0, sph = 0;
+        for (uint32_t k = 0; k < n_prims; k++) position[k] = prims[k].index < n_tris ? t++ : n_tris + sph++;
+    }
+    out.sph_leaf.resize(out.n_tree_spheres);
+    out.sph_orig.resize(out.n_tree_spheres);
 
     // Leaf-ordered intersection records.
     out.tri_isect.resize((size_t)n_tris * kTriRecord);
     out.tri_orig.resize(n_tris);
     out.tri_shade_leaf.resize((size_t)n_tris * 3);
-    for (uint32_t k = 0; k < n_tris; k++) {
-        const float *r = T + (size_t)prims[k].index * 24;
+    for (uint32_t at = 0; at < n_prims; at++) {
+        const uint32_t k = position[at];
+        if (prims[at].index >= n_tris) {
+            uint32_t which = prims[at].index - n_tris;
+            out.sph_leaf[k - n_tris] = out.spheres[4 * (size_t)which];
+            out.sph_orig[k - n_tris] = which;
+            continue;
+        }
+        const float *r = T + (size_t)prims[at].index * 24;
         f3 v0 = ld3(r), v1 = ld3(r + 4), v2 = ld3(r + 8);
         f3 e01 = sub(v1, v0), e02 = sub(v2, v0); // common.wgsl:172-173
         out.tri_isect[kTriRecord * (size_t)k + 0] = mk4(v0, e01.x);
         out.tri_isect[kTriRecord * (size_t)k + 1] = mk4(e01.y, e01.z, e02.x, e02.y);
-        const f4 *sh = &out.tri_shade[3 * (size_t)prims[k].index];
+        const f4 *sh = &out.tri_shade[3 * (size_t)prims[at].index];
         out.tri_isect[kTriRecord * (size_t)k + 2] = mk4(e02.z, sh[0].x, sh[0].y, sh[0].z);
-        out.tri_orig[k] = prims[k].index;
+        out.tri_orig[k] = prims[at].index;
         for (int j = 0; j < 3; j++) out.tri_shade_leaf[3 * (size_t)k + j] = sh[j];
     }
 
@@ -326,7 +374,7 @@ void build_scene(const void *spheres, uint32_t n_spheres, const void *triangles,
         else out.n_leaves++;
     out.nodes.assign((size_t)n_inner * 4, mk4(0, 0, 0, 0));
     auto link_of = [&](int32_t bi) -> int32_t {
-        return bn[bi].child[0] >= 0 ? flat_index[bi] : leaf_link(bn[bi].first, bn[bi].count);
+        return bn[bi].child[0] >= 0 ? flat_index[bi] : leaf_link(position[bn[bi].first], bn[bi].count);
     };
     for (size_t i = 0; i < bn.size(); i++) {
         if (bn[i].child[0] < 0) continue;
@@ -493,7 +541,7 @@ void build_scene(const void *spheres, uint32_t n_spheres, const void *triangles,
                 const Box &cb = bn[w.child[k]].box;
                 for (int a = 0; a < 3; a++) { v[a][k] = cb.lo[a]; v[3 + a][k] = cb.hi[a]; }
                 int32_t c = w.child[k];
-                link[k] = (uint32_t)(bn[c].child[0] >= 0 ? number_of[wide_of[c]] : leaf_link(bn[c].first, bn[c].count));
+                link[k] = (uint32_t)(bn[c].child[0] >= 0 ? number_of[wide_of[c]] : leaf_link(position[bn[c].first], bn[c].count));
             } else {
                 for (int a = 0; a < 3; a++) { v[a][k] = 0.0f; v[3 + a][k] = 0.0f; }
                 link[k] = (uint32_t)kNoRoot;

@@ -14,6 +14,12 @@ namespace rt {
 struct BuiltScene {
     std::vector<f4> nodes, nodes4, nodes4q, tri_isect, tri_shade, tri_shade_leaf, tri_raw, spheres, lights;
     std::vector<uint32_t> tri_orig; // original index of the triangle at each leaf position
+    // Spheres that are leaves of the tree (all of them, when there are more than BuildOptions::linear_spheres):
+    // (centre, radius) in leaf order and the original index of each.  Leaf positions n_tris .. n_tris +
+    // n_tree_spheres - 1 stand for them in the child links.
+    std::vector<f4> sph_leaf;
+    std::vector<uint32_t> sph_orig;
+    uint32_t n_tree_spheres = 0;
     uint32_t n_spheres = 0, n_tris = 0, n_lights = 0, n_lights_pass1 = 0;
     float total_power = 0.0f;
     int32_t root = kNoRoot, root4 = kNoRoot;
@@ -35,6 +41,7 @@ struct BuildOptions {
     bool greedy_collapse = false; // 4-wide tree by expanding the child of largest area instead of the cost-optimal cut
     // Stack entries of the fastest kernel variant: if only the cost-optimal cut needs more, the greedy one is taken.
     uint32_t prefer_stack = 22;
+    uint32_t linear_spheres = 8; // up to this many spheres are tested one by one per ray; more go into the tree as leaves
     bool quant_nodes = false; // also build the 64-byte form of the 4-wide nodes (BuiltScene::nodes4q)
     bool pack_links = true;   // write 16-bit child links into the low bytes of the node planes when they fit
     // Largest coordinate magnitude of any ray origin the tree must serve (camera position, scene

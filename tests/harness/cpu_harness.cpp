@@ -132,7 +132,7 @@ extern "C" int har_render_frame(const void *uniforms80, const void *spheres, uin
     fp.sphere_lights = g_sphere_lights ? 1u : 0u;
     rt::SceneView sc{};
     sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.nodes4q = bs.nodes4q.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data(); sc.tri_shade_leaf = bs.tri_shade_leaf.data(); sc.tri_orig = bs.tri_orig.data();
-    sc.tri_raw = bs.tri_raw.data(); sc.spheres = bs.spheres.data(); sc.lights = bs.lights.data();
+    sc.tri_raw = bs.tri_raw.data(); sc.spheres = bs.spheres.data(); sc.lights = bs.lights.data(); sc.sph_leaf = bs.sph_leaf.data(); sc.sph_orig = bs.sph_orig.data(); sc.n_linear_spheres = bs.n_spheres - bs.n_tree_spheres;
     sc.n_spheres = bs.n_spheres; sc.n_tris = bs.n_tris; sc.n_lights = bs.n_lights;
     sc.n_lights_pass1 = bs.n_lights_pass1; sc.total_power = bs.total_power; sc.root = bs.root;
 
@@ -192,7 +192,7 @@ extern "C" int har_debug_pixel(const void *uniforms80, const void *spheres, uint
     if (!rt::make_frame_params(uniforms80, max_bounces, fp, err)) return -1;
     rt::SceneView sc{};
     sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.nodes4q = bs.nodes4q.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data(); sc.tri_shade_leaf = bs.tri_shade_leaf.data(); sc.tri_orig = bs.tri_orig.data();
-    sc.tri_raw = bs.tri_raw.data(); sc.spheres = bs.spheres.data(); sc.lights = bs.lights.data();
+    sc.tri_raw = bs.tri_raw.data(); sc.spheres = bs.spheres.data(); sc.lights = bs.lights.data(); sc.sph_leaf = bs.sph_leaf.data(); sc.sph_orig = bs.sph_orig.data(); sc.n_linear_spheres = bs.n_spheres - bs.n_tree_spheres;
     sc.n_spheres = bs.n_spheres; sc.n_tris = bs.n_tris; sc.n_lights = bs.n_lights;
     sc.n_lights_pass1 = bs.n_lights_pass1; sc.total_power = bs.total_power; sc.root = bs.root;
     HostStack st;
@@ -266,7 +266,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
     if (!rt::make_frame_params(uni, max_bounces, fp, err)) return -1;
     rt::SceneView sc{};
     sc.nodes = bs.nodes.data(); sc.nodes4 = bs.nodes4.data(); sc.nodes4q = bs.nodes4q.data(); sc.root4 = bs.root4; sc.tri_isect = bs.tri_isect.data(); sc.tri_shade = bs.tri_shade.data(); sc.tri_shade_leaf = bs.tri_shade_leaf.data(); sc.tri_orig = bs.tri_orig.data();
-    sc.tri_raw = bs.tri_raw.data(); sc.spheres = bs.spheres.data(); sc.lights = bs.lights.data();
+    sc.tri_raw = bs.tri_raw.data(); sc.spheres = bs.spheres.data(); sc.lights = bs.lights.data(); sc.sph_leaf = bs.sph_leaf.data(); sc.sph_orig = bs.sph_orig.data(); sc.n_linear_spheres = bs.n_spheres - bs.n_tree_spheres;
     sc.n_spheres = bs.n_spheres; sc.n_tris = bs.n_tris; sc.n_lights = bs.n_lights;
     sc.n_lights_pass1 = bs.n_lights_pass1; sc.total_power = bs.total_power; sc.root = bs.root;
 
@@ -343,7 +343,7 @@ extern "C" int har_render_frames_lanes(const void *uniforms80, const void *spher
                     for (int i = 0; i < 64; i++)
                         if (L[i].mode == rt::kLaneTraverse && rt::link_is_leaf(L[i].cur)) {
                             uint32_t code = (uint32_t)~L[i].cur;
-                            if ((code >> 3) + (code & 7u) >= bs.n_tris) { bad_links++; L[i].cur = rt::kNoRoot; L[i].mode = rt::kLaneShadeClosest; continue; }
+                            if ((code >> 3) + (code & 7u) >= bs.n_tris + bs.n_tree_spheres) { bad_links++; L[i].cur = rt::kNoRoot; L[i].mode = rt::kLaneShadeClosest; continue; }
                             rt::lane_step_triangle(sc, L[i], st[i], &cnt);
                         }
                 for (int i = 0; i < 64; i++)

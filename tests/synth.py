@@ -108,3 +108,27 @@ def card_deck_scene(n_cards: int) -> S.Scene:
         tris.append(dict(v0=a, v1=b, v2=c, **mat))           # counter-clockwise seen from +z: faces the camera
         tris.append(dict(v0=a, v1=c, v2=d, **mat))
     return S.Scene(camera=base.camera, spheres=base.spheres, triangles=tris)
+
+
+def sphere_field_scene(n: int, with_triangles: bool = True) -> S.Scene:
+    """n spheres on a deterministic lattice inside scene_boxes' room (more than a ray tests one by one, so they
+    become leaves of the acceleration structure), of varied size and material, some emissive, some mirrors, the
+    last two coincident with earlier ones (ties in t: the lower index must be reported), one enclosing the
+    camera's near field partly (the t2 branch of the sphere test).  No random numbers."""
+    import copy
+
+    boxes = S.load_scene(S.scene_path("boxes"))
+    spheres = []
+    for k in range(n):
+        i, j, l = k % 7, (k // 7) % 5, k // 35
+        spheres.append(dict(center=[-2.1 + 0.7 * i + 0.05 * l, 0.25 + 0.75 * j, -0.8 - 0.9 * l - 0.1 * i],
+                            radius=0.08 + 0.02 * ((k * 5) % 9),
+                            color=[0.25 + 0.1 * (k % 7), 0.9 - 0.08 * (k % 9), 0.35 + 0.05 * (k % 11)],
+                            smoothness=0.125 * (k % 9), emissionColor=[1.0, 0.8, 0.6],
+                            emissionStrength=2.5 if k % 23 == 4 else 0.0, specularProbability=0.1 * (k % 11)))
+    if n >= 12:
+        spheres[-1] = copy.deepcopy(spheres[3])
+        spheres[-2] = copy.deepcopy(spheres[10])
+        spheres[5]["center"] = [0.0, 2.5, 4.0]   # one unit in front of the camera (scene_boxes: position 0, 2.5, 5)
+        spheres[5]["radius"] = 0.995
+    return S.Scene(camera=boxes.camera, spheres=spheres, triangles=boxes.triangles if with_triangles else [])

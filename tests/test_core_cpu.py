@@ -189,6 +189,31 @@ def test_sphere_light_extension_in_the_lane_state_machine():
         assert int(har.counters[0]) == int(orc.counters[0])
 
 
+@pytest.mark.parametrize("n,with_triangles", [(9, True), (60, True), (150, False)])
+def test_spheres_as_leaves_of_the_tree(n, with_triangles):
+    """More than eight spheres go into the acceleration structure as leaves of their own kind.  Both traversals
+    of the shared core (the one-thread-per-pixel loop and the lane state machine) against the oracle, which
+    tests every sphere per ray as the reference does: ids (original sphere indices, spheres before
+    triangles on ties), frame, accumulator, ray count; with and without triangles in the scene."""
+    from tests.synth import sphere_field_scene
+
+    scene = sphere_field_scene(n, with_triangles)
+    orc = O.OracleRenderer(scene, 64, 36)
+    orc.set_samples_per_pixel(2)
+    orc.render_frames(2)
+    assert (orc.ids >= 0).any() and (orc.ids < n).any()
+    har = HarnessRenderer(scene, 64, 36)
+    for _ in range(2):
+        har.render(2)
+    lanes = HarnessRenderer(scene, 64, 36)
+    lanes.render_frames_lanes(2, 1, 2, packed_links=True)
+    for got in (har, lanes):
+        assert np.array_equal(got.ids, orc.ids)
+        assert np.array_equal(got.frame_f16, orc.frame_f16)
+        assert np.array_equal(got.accum, orc.accum)
+        assert int(got.counters[0]) == int(orc.counters[0])
+
+
 def test_64_byte_nodes_enclose_the_128_byte_ones(scenes):
     from raytracer_amd import scene as S
     from tests.harness_lib import lib

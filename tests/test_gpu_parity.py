@@ -438,6 +438,20 @@ def test_sphere_light_extension(mode):
         ctx.close()
 
 
+@pytest.mark.parametrize("n,with_triangles", [(9, True), (60, True), (150, False), (5000, True)])
+def test_spheres_as_leaves_of_the_tree(n, with_triangles):
+    """Scenes of more than eight spheres: the spheres are leaves of the acceleration structure instead of a
+    list every ray walks.  All three modes against the oracle (which walks the list, as the reference does);
+    5000 spheres exceed the 4096 leaf positions of the 16-bit links, i.e. take the large-scene kernel."""
+    from tests.synth import sphere_field_scene
+
+    scene = sphere_field_scene(n, with_triangles)
+    width, height, spp = (64, 36, 2) if n <= 150 else (40, 23, 1)
+    for mode in (capi.RT_MODE_BVH, capi.RT_MODE_BVH_TILES, capi.RT_MODE_BRUTE_FORCE):
+        run_pair(scene, width, height, 2, spp, mode)
+    run_batched(scene, width, height, 3, spp, 2)
+
+
 @pytest.mark.parametrize("distance,fov", [(1000.0, 0.4), (30000.0, 0.013)])
 def test_far_camera_bvh_vs_brute_force_and_oracle(scenes, distance, fov):
     """A camera thousands of units from the geometry, zoomed in: the f32 slack of the triangle test
