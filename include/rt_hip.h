@@ -234,6 +234,20 @@ int rt_last_render_frames(rt_context *ctx, uint32_t *frames);
  */
 int rt_read_accum(rt_context *ctx, float *rgb);
 
+/*
+ * The image the accumulator pass shows on the canvas (`return vec4(accumulatedColor, 1.0)`,
+ * public/accumulator.wgsl:67, src/accumulator.ts:63-78): width*height RGBA8, value * 255 rounded to nearest,
+ * alpha 255, no gamma; rows the context does not own are black.  The reference presents every frame and never
+ * waits for it; neither does this call with wait = 0: it asks for the image of the frames launched so far
+ * (converted on the GPU behind them, copied to pinned host memory on a stream of its own), copies the newest image
+ * that has already arrived into `rgba8` and returns at once; *frame_index (may be NULL) receives the frameIndex
+ * that image ends with, 0 if none has arrived yet (`rgba8` is then left as it is).  Frames rt_render_frame still
+ * holds back are not launched for it: a render loop that presents every frame keeps its batching, and the canvas
+ * runs a launch or two behind, as a swap chain does.  wait != 0: launches what is held back, waits, and returns
+ * the image of everything submitted.
+ */
+int rt_present(rt_context *ctx, uint8_t *rgba8, int wait, uint32_t *frame_index);
+
 /* Inverse of rt_read_accum: replace the accumulator planes by width*height
  * interleaved RGB float32 from host memory, and wait for the copy.  No
  * counterpart in the reference.  For hosts without device buffers of their own

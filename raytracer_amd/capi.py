@@ -49,6 +49,7 @@ SYMBOLS = {
     "rt_last_render_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "rt_last_render_frames": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "rt_read_accum": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_present": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]),
     "rt_write_accum": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_read_frame_f16": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_read_primary_ids": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -196,6 +197,15 @@ class Context:
         out = np.empty((self.height, self.width, 3), dtype=np.float32)
         _check(self.lib.rt_read_accum(self.handle, _ptr(out)))
         return out
+
+    def present(self, out: np.ndarray = None, wait: bool = False):
+        """(RGBA8 image (H, W, 4), frameIndex it ends with); wait=False: the newest image that has arrived."""
+        if out is None:
+            out = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        assert out.dtype == np.uint8 and out.size == self.width * self.height * 4 and out.flags["C_CONTIGUOUS"]
+        frame = C.c_uint32()
+        _check(self.lib.rt_present(self.handle, _ptr(out), 1 if wait else 0, C.byref(frame)))
+        return out, frame.value
 
     def write_accum(self, rgb: np.ndarray):
         rgb = np.ascontiguousarray(rgb, dtype=np.float32)

@@ -856,6 +856,22 @@ __global__ __launch_bounds__(256) void order_tiles_kernel(const unsigned int *co
     }
 }
 
+// The canvas output of the accumulator pass (`return vec4(accumulatedColor, 1.0)`, accumulator.wgsl:67, into an
+// 8-bit unorm target): RGBA8 of the accumulator planes, no gamma; value * 255 rounded to nearest.
+__global__ void present_rgba8_kernel(const float *accum, uint32_t *rgba, size_t px)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= px) return;
+    uint32_t out = 0xff000000u;
+    for (int ch = 0; ch < 3; ch++) {
+        float v = accum[ch * px + i];
+        double scaled = floor((double)v * 255.0 + 0.5);
+        uint32_t q = scaled >= 0.0 && scaled <= 255.0 ? (uint32_t)scaled : (scaled > 255.0 ? 255u : 0u); // NaN -> 0
+        out |= q << (8 * ch);
+    }
+    rgba[i] = out;
+}
+
 __global__ void fill_i32_kernel(int32_t *p, int32_t v, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -963,6 +979,18 @@ struct rt_context {
     unsigned int *d_tile_cost[1 + kMaxSlots][2] = {};
     uint32_t *d_tile_order[1 + kMaxSlots] = {}, *d_tile_cls[1 + kMaxSlots] = {};
     int tile_cost_phase[1 + kMaxSlots] = {};
+    // Presented image (rt_present): two slots, each a device block, a pinned host block and the event that ends its
+    // copy; the copies run on a stream of their own.
+    hipStream_t copy_stream = nullptr;
+    uint32_t *d_present[2] = {nullptr, nullptr};
+    uint32_t *h_present[2] = {nullptr, nullptr};
+    hipEvent_t present_ready[2] = {nullptr, nullptr}, present_done[2] = {nullptr, nullptr};
+    bool present_used[2] = {false, false};
+    uint64_t present_serial[2] = {0, 0}; // launch_serial at the time the slot's image was asked for
+    uint32_t present_frame[2] = {0, 0};  // frameIndex of the last frame in that image
+    int present_next = 0;
+    uint64_t launch_serial = 0;          // counts render launches; says whether the planes changed since the last present
+    uint32_t launched_frame = 0;         // frameIndex of the last frame launched
     int tune_tile_order = 1;
     int tune_linear_spheres = 8;
     int next_slot = 0;
@@ -1494,6 +1522,13 @@ void rt_destroy(rt_context *c)
     }
     for (hipEvent_t e : c->flush_done)
         if (e) (void)hipEventDestroy(e);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    for (int k = 0; k < 2; k++) {
+        (void)hipFree(c->d_present[k]);
+        if (c->h_present[k]) (void)hipHostFree(c->h_present[k]);
+        if (c->present_ready[k]) (void)hipEventDestroy(c->present_ready[k]);
+        if (c->present_done[k]) (void)hipEventDestroy(c->present_done[k]);
+    }
     for (int32_t *p : c->d_spill) (void)hipFree(p);
     for (int k = 0; k <= rt_context::kMaxSlots; k++) {
         (void)hipFree(c->d_tile_cost[k][0]); (void)hipFree(c->d_tile_cost[k][1]);
@@ -1700,6 +1735,7 @@ static int render_frames_impl(rt_context *c, uint32_t first_frame_index, uint32_
     RT_HIP_CHECK(hipEventRecord(c->ev_stop, c->stream));
     c->timed = true;
     c->timed_frames = n_frames;
+    if (n_frames) { c->launch_serial++; c->launched_frame = first_frame_index + (n_frames - 1) * stride; }
     return RT_OK;
 }
 
@@ -1861,6 +1897,57 @@ int rt_write_accum(rt_context *c, const float *rgb)
     }
     RT_HIP_CHECK(hipMemcpyAsync(c->fb.accum, planes.data(), px * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     RT_HIP_CHECK(hipStreamSynchronize(c->stream)); // `planes` goes out of scope
+    return RT_OK;
+}
+
+int rt_present(rt_context *c, uint8_t *rgba8, int wait, uint32_t *frame_index)
+{
+    if (!c || !rgba8) return fail(RT_ERR_INVALID, "null argument");
+    if (wait) RT_FLUSH_PENDING(c);
+    RT_HIP_CHECK(hipSetDevice(c->device));
+    const size_t px = (size_t)c->width * c->height;
+    if (!c->copy_stream) {
+        RT_HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            RT_HIP_CHECK(hipMalloc((void **)&c->d_present[k], px * 4));
+            RT_HIP_CHECK(hipHostMalloc((void **)&c->h_present[k], px * 4, hipHostMallocDefault));
+            RT_HIP_CHECK(hipEventCreateWithFlags(&c->present_ready[k], hipEventDisableTiming));
+            RT_HIP_CHECK(hipEventCreateWithFlags(&c->present_done[k], hipEventDisableTiming));
+        }
+    }
+    // newest image asked for so far
+    int newest = -1;
+    for (int k = 0; k < 2; k++)
+        if (c->present_used[k] && (newest < 0 || c->present_serial[k] > c->present_serial[newest])) newest = k;
+    if (newest < 0 || c->present_serial[newest] != c->launch_serial) {
+        // the planes have changed since: convert on the context's stream, behind the frames launched so far, and copy
+        // to the host on the copy stream.  The slot taken is the older one; its previous copy is over by now, or waited for.
+        int k = c->present_next;
+        c->present_next ^= 1;
+        if (c->present_used[k]) RT_HIP_CHECK(hipEventSynchronize(c->present_done[k]));
+        hipLaunchKernelGGL(present_rgba8_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, c->stream, c->fb.accum, c->d_present[k], px);
+        RT_HIP_CHECK(hipGetLastError());
+        RT_HIP_CHECK(hipEventRecord(c->present_ready[k], c->stream));
+        RT_HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->present_ready[k], 0));
+        RT_HIP_CHECK(hipMemcpyAsync(c->h_present[k], c->d_present[k], px * 4, hipMemcpyDeviceToHost, c->copy_stream));
+        RT_HIP_CHECK(hipEventRecord(c->present_done[k], c->copy_stream));
+        // the next convert into this slot must not overtake the copy: the context's stream waits for it when the slot comes round
+        c->present_used[k] = true;
+        c->present_serial[k] = c->launch_serial;
+        c->present_frame[k] = c->launched_frame;
+        newest = k;
+    }
+    int from = -1;
+    if (wait) {
+        RT_HIP_CHECK(hipEventSynchronize(c->present_done[newest]));
+        from = newest;
+    } else {
+        // the newest image whose copy has arrived, without waiting
+        for (int k = 0; k < 2; k++)
+            if (c->present_used[k] && hipEventQuery(c->present_done[k]) == hipSuccess && (from < 0 || c->present_serial[k] > c->present_serial[from])) from = k;
+    }
+    if (from >= 0) std::memcpy(rgba8, c->h_present[from], px * 4);
+    if (frame_index) *frame_index = from >= 0 ? c->present_frame[from] : 0u;
     return RT_OK;
 }
 

@@ -4,9 +4,10 @@
  * async create, render) over the native context.  The three r32float planes
  * and the running-mean pass of public/accumulator.wgsl live inside the native
  * context and run as part of each frame submission, so render() has nothing
- * left to encode; what it still does is the pass's other output, the 8-bit
- * canvas image (`return vec4(accumulatedColor, 1.0)`, accumulator.wgsl:67),
- * when the caller hands it a pixel array in place of a canvas view.
+ * left to encode; what it still does is ask for the pass's other output, the
+ * 8-bit canvas image (`return vec4(accumulatedColor, 1.0)`,
+ * accumulator.wgsl:67), when the caller hands it a pixel array in place of a
+ * canvas view.
  */
 class Accumulator {
     constructor(native, handle, resolution) {
@@ -22,19 +23,14 @@ class Accumulator {
         return new Accumulator(device.native, device.handle, resolution);
     }
 
-    // src/accumulator.ts:63-78.  canvasView: optional Uint8Array / Uint8ClampedArray
-    // of width*height*4 that receives the presented image (RGBA8, no gamma).
-    render(commandEncoder, canvasView) {
-        if (!canvasView) return;
-        const w = this.resolution.width, h = this.resolution.height;
-        const acc = this.native.readAccum(this.handle, w, h);
-        for (let i = 0, n = w * h; i < n; i++) {
-            // 8-bit unorm store of a value already clamped to [0, 1]
-            canvasView[4 * i + 0] = Math.round(acc[3 * i + 0] * 255);
-            canvasView[4 * i + 1] = Math.round(acc[3 * i + 1] * 255);
-            canvasView[4 * i + 2] = Math.round(acc[3 * i + 2] * 255);
-            canvasView[4 * i + 3] = 255;
-        }
+    // src/accumulator.ts:63-78.  canvasView: optional Uint8Array / Uint8ClampedArray of width*height*4 that
+    // receives the presented image (RGBA8, no gamma), made on the GPU and copied to the host behind the frames
+    // launched so far.  Like the reference's canvas pass this does not wait for the GPU: the array receives the
+    // newest image that has arrived (none during the first frames); the return value is the frameIndex that image
+    // ends with.  wait = true: the image of every frame submitted so far, waited for.
+    render(commandEncoder, canvasView, wait) {
+        if (!canvasView) return 0;
+        return this.native.present(this.handle, canvasView, wait ? 1 : 0);
     }
 }
 

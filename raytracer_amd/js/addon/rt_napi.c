@@ -259,6 +259,34 @@ static napi_value js_last_render_ms(napi_env env, napi_callback_info info)
     return out;
 }
 
+/* (handle, Uint8Array or Uint8ClampedArray of width*height*4, wait) -> frameIndex the image ends with (0: none yet) */
+static napi_value js_present(napi_env env, napi_callback_info info)
+{
+    napi_value a[3], out;
+    if (!get_args(env, info, 3, a)) return NULL;
+    NEED_CTX(ctx, a[0]);
+    handle_box *box = get_box(env, a[0]);
+    napi_typedarray_type type;
+    napi_value ab;
+    size_t len, off;
+    void *p;
+    if (napi_get_typedarray_info(env, a[1], &type, &len, &p, &ab, &off) != napi_ok ||
+        (type != napi_uint8_array && type != napi_uint8_clamped_array)) {
+        napi_throw_type_error(env, NULL, "expected a Uint8Array or Uint8ClampedArray");
+        return NULL;
+    }
+    if (len != (size_t)box->width * box->height * 4) {
+        napi_throw_range_error(env, NULL, "expected width * height * 4 bytes");
+        return NULL;
+    }
+    int32_t wait;
+    if (!get_i32(env, a[2], &wait)) return NULL;
+    uint32_t frame = 0;
+    if (rt_present(ctx, (uint8_t *)p, wait, &frame) != RT_OK) return throw_rt(env, "rt_present");
+    NAPI_OK(napi_create_uint32(env, frame, &out));
+    return out;
+}
+
 static napi_value js_last_render_frames(napi_env env, napi_callback_info info)
 {
     napi_value a[1], out;
@@ -455,7 +483,7 @@ static napi_value init(napi_env env, napi_value exports)
         {"renderFrame", js_render_frame}, {"renderFrames", js_render_frames}, {"sync", js_sync},
         {"lastRenderMs", js_last_render_ms}, {"readAccum", js_read_accum}, {"readFrameF16", js_read_frame_f16},
         {"readPrimaryIds", js_read_primary_ids}, {"readCounters", js_read_counters},
-        {"lastRenderFrames", js_last_render_frames}, {"clearAccum", js_clear_accum}, {"renderFrameSums", js_render_frame_sums},
+        {"present", js_present}, {"lastRenderFrames", js_last_render_frames}, {"clearAccum", js_clear_accum}, {"renderFrameSums", js_render_frame_sums},
         {"finishFrameSums", js_finish_frame_sums}, {"writeAccum", js_write_accum},
         {"takeTriangleTests", js_take_triangle_tests}, {"ownedRows", js_owned_rows}, {"sceneStats", js_scene_stats},
     };

@@ -16,6 +16,8 @@
  * GPUs instead (whole images per GPU, sums added at the end: approximate, see include/rt_hip.h).
  *
  * --preview-every k rewrites the image file after every k frames (progressive preview).
+ * --present-every k renders frame by frame, as the reference's render loop does, and fills the canvas
+ * image after every k-th frame without waiting for the GPU (k = 1: the reference's canvas pass).
  */
 const fs = require('fs');
 const { HipRenderer } = require('./hip-renderer');
@@ -38,6 +40,7 @@ function parseArgs(argv) {
         else if (k === '--bounces') a.bounces = parseInt(v, 10);
         else if (k === '--ppm' || k === '--image') a.ppm = v;
         else if (k === '--preview-every') a.previewEvery = parseInt(v, 10);
+        else if (k === '--present-every') a.presentEvery = parseInt(v, 10);
         else if (k === '--dump') a.dump = v;
         else if (k === '--split') a.split = v;
         else if (k === '--devices') a.devices = v.split(',').map((x) => parseInt(x, 10));
@@ -69,9 +72,10 @@ async function mainSplit(a) {
 async function main() {
     const a = parseArgs(process.argv);
     if (a.devices && a.devices.length > 1) return mainSplit(a);
-    const canvas = { width: a.width, height: a.height, pixels: a.ppm ? new Uint8Array(a.width * a.height * 4) : null };
-    // the canvas image is only needed when a file is written: fill it on demand, not on every frame
-    const renderer = await HipRenderer.Create(canvas, a.scene, { maxBounces: a.bounces, presentEvery: 1 << 30,
+    const canvas = { width: a.width, height: a.height, pixels: a.ppm || a.presentEvery ? new Uint8Array(a.width * a.height * 4) : null };
+    // without --present-every the canvas image is only needed when a file is written: filled on demand, not on every frame
+    if (a.presentEvery) a.perFrame = true;
+    const renderer = await HipRenderer.Create(canvas, a.scene, { maxBounces: a.bounces, presentEvery: a.presentEvery || (1 << 30),
                                                                  applyModelTransforms: a.applyModelTransforms,
                                                                  sphereLights: a.sphereLights, debugView: a.debugView });
     if (!renderer) process.exit(1);
@@ -79,7 +83,7 @@ async function main() {
     if (a.debugView) renderer.setDebug(true);
     const t0 = process.hrtime.bigint();
     const present = () => {
-        renderer.accumulator.render(null, canvas.pixels);
+        renderer.presentNow();
         writeImage(a.ppm, canvas.pixels, a.width, a.height);
     };
     const chunk = a.ppm && a.previewEvery > 0 ? a.previewEvery : a.frames;

@@ -50,6 +50,7 @@ export class HipRenderer {
     readFrameF16(): Uint16Array;
     getCounters(): number[];
     lastRenderMs(): number;
+    presentNow(): number;
     lastRenderFrames(): number;
     clearAccum(): void;
     renderFrameSums(firstFrameIndex: number, nFrames: number, stride?: number): void;

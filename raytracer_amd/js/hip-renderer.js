@@ -46,7 +46,8 @@ class HipRenderer {
     // triangle's normal marker (the shader's unused ray_triangle_normal_intersect; off by default: the reference's
     // setDebug changes nothing on screen); applyModelTransforms applies a model's scale / rotation / position, which the
     // reference reads and ignores (off by default); presentEvery = k copies the image into canvas.pixels on every k-th frame only (default 1,
-    // every frame as the reference's canvas pass does; the copy reads the accumulator back and so waits for the GPU)
+    // every frame as the reference's canvas pass does; like that pass it does not wait for the GPU: canvas.pixels shows the newest
+    // image that has arrived, a launch or two behind the frames submitted; presentNow() waits for the current one)
     static async Create(canvas, scenePath, options) {
         const renderer = new HipRenderer(canvas);
         const opt = options || {};
@@ -176,6 +177,12 @@ class HipRenderer {
 
     sync() {
         this.native.sync(this.handle);
+    }
+
+    // The image of every frame submitted so far in canvas.pixels (waits for the GPU); returns the frameIndex it ends with.
+    presentNow() {
+        if (!this.accumulator || !this.canvas.pixels) return 0;
+        return this.accumulator.render(null, this.canvas.pixels, true);
     }
 
     readAccum() {

@@ -580,3 +580,41 @@ def test_host_staged_row_exchange(scenes):
         ctxs[0].rows_of_stripe(count)
     for ctx in ctxs:
         ctx.close()
+
+
+def test_presented_image(scenes):
+    """rt_present: the canvas image of the accumulator pass (RGBA8, value * 255 rounded, no gamma).  Waited
+    for, it is the image of everything submitted; not waited for, it is some earlier frame's image, complete and
+    labelled with that frame's index, and catches up once the GPU has."""
+    scene = scenes["boxes"]
+    width, height, spp, frames = 96, 54, 2, 6
+    orc = O.OracleRenderer(scene, width, height)
+    orc.set_samples_per_pixel(spp)
+    want = {}
+    for f in range(1, frames + 1):
+        orc.render()
+        img = np.full((height, width, 4), 255, np.uint8)
+        img[:, :, :3] = np.floor(orc.accum_rgb().astype(np.float64) * 255 + 0.5).astype(np.uint8)
+        want[f] = img
+    ctx = capi.Context(width, height)
+    ctx.set_scene(S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles))
+    seen = []
+    for f in range(1, frames + 1):
+        ctx.set_uniforms(S.pack_uniforms(scene.camera, f, width, height, spp))
+        ctx.render_frame()
+        img, at = ctx.present(wait=False)
+        assert at <= f
+        if at:
+            assert np.array_equal(img, want[at]), "image labelled frame %d is not that frame's" % at
+            seen.append(at)
+    assert seen == sorted(seen)
+    img, at = ctx.present(wait=True)
+    assert at == frames and np.array_equal(img, want[frames])
+    img, at = ctx.present(wait=False)          # nothing new: the same image again, no new conversion
+    assert at == frames and np.array_equal(img, want[frames])
+    ctx.render_frames(frames + 1, 2)
+    orc.render_frames(2)
+    img, at = ctx.present(wait=True)
+    assert at == frames + 2
+    assert np.array_equal(img[:, :, :3], np.floor(orc.accum_rgb().astype(np.float64) * 255 + 0.5).astype(np.uint8))
+    ctx.close()

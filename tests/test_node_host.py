@@ -109,7 +109,7 @@ def test_addon_exports_the_abi():
     names = json.loads(node(script))
     for n in ["setSphereLights", "create", "destroy", "setScene", "setUniforms", "renderFrame", "renderFrames", "readAccum",
               "readPrimaryIds", "readFrameF16", "takeTriangleTests", "readCounters", "deviceCount", "sync",
-              "clearAccum", "renderFrameSums", "finishFrameSums", "writeAccum", "lastRenderFrames"]:
+              "clearAccum", "renderFrameSums", "finishFrameSums", "writeAccum", "lastRenderFrames", "present"]:
         assert n in names
 
 
@@ -160,7 +160,7 @@ def test_js_render_loop_runs_unfenced_and_in_order(scenes, tmp_path):
 const fs = require('fs');
 const { HipRenderer } = require('%(js)s/hip-renderer');
 const canvas = { width: %(w)d, height: %(h)d, pixels: new Uint8Array(%(w)d * %(h)d * 4) };
-HipRenderer.Create(canvas, '%(scene)s', { presentEvery: 4 }).then((r) => {
+HipRenderer.Create(canvas, '%(scene)s', { presentEvery: 1 }).then((r) => {
   r.setSamplesPerPixel(%(spp)d);
   r.startRenderLoop();
   const poll = () => {
@@ -168,7 +168,9 @@ HipRenderer.Create(canvas, '%(scene)s', { presentEvery: 4 }).then((r) => {
     r.stopRenderLoop();
     r.sync();
     fs.writeFileSync('%(out)s', Buffer.from(r.readAccum().buffer));
-    console.log(JSON.stringify({ frames: r.frameIndex, fps: r.getFPS() }));
+    const shown = r.presentNow();
+    fs.writeFileSync('%(out)s.rgba', Buffer.from(canvas.pixels.buffer));
+    console.log(JSON.stringify({ frames: r.frameIndex, fps: r.getFPS(), shown: shown }));
     r.destroy();
   };
   setImmediate(poll);
@@ -181,6 +183,11 @@ HipRenderer.Create(canvas, '%(scene)s', { presentEvery: 4 }).then((r) => {
     orc.render_frames(info["frames"])
     acc = np.fromfile(tmp_path / "loop.f32", np.float32).reshape(height, width, 3)
     assert np.array_equal(acc, orc.accum_rgb())
+    # the canvas image (presented every frame without waiting during the loop, then once waited for)
+    shown = np.fromfile(str(tmp_path / "loop.f32") + ".rgba", np.uint8).reshape(height, width, 4)
+    assert info["shown"] == info["frames"]
+    assert np.array_equal(shown[:, :, :3], np.floor(orc.accum_rgb().astype(np.float64) * 255 + 0.5).astype(np.uint8))
+    assert (shown[:, :, 3] == 255).all()
 
 
 @pytest.mark.gpu
