@@ -137,8 +137,10 @@ int rt_set_max_bounces(rt_context *ctx, uint32_t max_bounces);
  * (public/raytracer_compute.wgsl:109-171) and a TODO where it should be called
  * (:226) but never calls it; with this switch it is called right after the
  * triangle-light block (:211-225) and used the same way (one more shadow ray,
- * same MIS weight).  Frames rendered with it go through the
- * one-thread-per-pixel kernel (RT_MODE_BVH behaves as RT_MODE_BVH_TILES).
+ * same MIS weight).  Scenes of up to 4096 primitives are rendered by the
+ * persistent kernel, which sets the bounce's second shadow ray aside while the
+ * first is traced; larger ones go through the one-thread-per-pixel kernel
+ * (RT_MODE_BVH behaves as RT_MODE_BVH_TILES).
  */
 int rt_set_sphere_lights(rt_context *ctx, int enable);
 
