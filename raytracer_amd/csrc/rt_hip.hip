@@ -994,7 +994,7 @@ struct rt_context {
     uint64_t present_serial[2] = {0, 0}; // launch_serial at the time the slot's image was asked for
     uint32_t present_frame[2] = {0, 0};  // frameIndex of the last frame in that image
     int present_next = 0;
-    uint64_t launch_serial = 0;          // counts render launches; says whether the planes changed since the last present
+    uint64_t launch_serial = 0;          // counts the calls that changed the accumulator planes (launches, imports, clears): has the image changed since the last present?
     uint32_t launched_frame = 0;         // frameIndex of the last frame launched
     int tune_tile_order = 1;
     int tune_linear_spheres = 8;
@@ -1779,6 +1779,7 @@ int rt_clear_accum(rt_context *c)
     RT_FLUSH_PENDING(c);
     RT_HIP_CHECK(hipSetDevice(c->device));
     RT_HIP_CHECK(hipMemsetAsync(c->fb.accum, 0, (size_t)c->width * c->height * 3 * sizeof(float), c->stream));
+    c->launch_serial++; // the planes changed: the next rt_present makes a new image
     return RT_OK;
 }
 
@@ -1799,6 +1800,7 @@ int rt_import_accum(rt_context *c, const void *src_device)
     RT_HIP_CHECK(hipSetDevice(c->device));
     RT_HIP_CHECK(hipMemcpyAsync(c->fb.accum, src_device, (size_t)c->width * c->height * 3 * sizeof(float),
                                 hipMemcpyDeviceToDevice, c->stream));
+    c->launch_serial++; // the planes changed: the next rt_present makes a new image
     return RT_OK;
 }
 
@@ -1811,6 +1813,7 @@ int rt_finish_frame_sums(rt_context *c, uint32_t n_frames_total)
     hipLaunchKernelGGL(finish_sums_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->fb.accum, n,
                        (float)n_frames_total + 1.0f);
     RT_HIP_CHECK(hipGetLastError());
+    c->launch_serial++; // the planes changed: the next rt_present makes a new image
     return RT_OK;
 }
 
@@ -1902,6 +1905,7 @@ int rt_write_accum(rt_context *c, const float *rgb)
     }
     RT_HIP_CHECK(hipMemcpyAsync(c->fb.accum, planes.data(), px * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     RT_HIP_CHECK(hipStreamSynchronize(c->stream)); // `planes` goes out of scope
+    c->launch_serial++; // the planes changed: the next rt_present makes a new image
     return RT_OK;
 }
 
@@ -2075,6 +2079,7 @@ int rt_import_rows(rt_context *c, const void *src_device, int from_index)
     hipLaunchKernelGGL(import_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->fb.accum,
                        (const float *)src_device, c->width, c->height, rows, sm, n);
     RT_HIP_CHECK(hipGetLastError());
+    c->launch_serial++; // the planes changed: the next rt_present makes a new image
     return RT_OK;
 }
 
@@ -2101,6 +2106,7 @@ int rt_import_gathered_rows(rt_context *c, const void *src_device, int rows_per_
                            (size_t)rows_per_block * c->width);
         RT_HIP_CHECK(hipGetLastError());
     }
+    c->launch_serial++; // the planes changed: the next rt_present makes a new image
     return RT_OK;
 }
 
