@@ -7,7 +7,7 @@ native context, which owns the three accumulation planes.  The JavaScript
 drop-in with the identical surface lives in raytracer_amd/js/.
 
 Additions the reference lacks (it only ever presents to a canvas):
-``render_frames``, ``read_accum``, ``read_ids``, ``read_frame_f16``, ``sync``.
+``render_frames``, ``present``, ``read_accum``, ``read_ids``, ``read_frame_f16``, ``sync``.
 """
 from __future__ import annotations
 
@@ -151,6 +151,12 @@ class HipRenderer:
 
     def sync(self):
         self.ctx.sync()
+
+    def present(self, out: Optional[np.ndarray] = None, wait: bool = False):
+        """The canvas image (what src/accumulator.ts:119-136 draws: the accumulated colour, clamped, 8 bits per
+        channel) as an (H, W, 4) uint8 array, and the frameIndex it ends with.  ``wait=False`` never waits for the
+        GPU: it returns the newest image that has arrived and starts the copy of the current one."""
+        return self.ctx.present(out, wait)
 
     def read_accum(self) -> np.ndarray:
         return self.ctx.read_accum()

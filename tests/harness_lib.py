@@ -63,7 +63,7 @@ class HarnessRenderer:
         child links are read as the kernels read them for this scene (from the low bytes of the node
         planes when the builder packed them there); returns the link width used (0 or 16)."""
         u = self.S.pack_uniforms(self.scene.camera, first_frame, self.width, self.height, spp)
-        # quant_nodes: the lanes visit the 64-byte nodes (the kernels' node form for scenes of more than 4096 triangles)
+        # quant_nodes: the lanes visit the 64-byte nodes (a build option of the large-scene kernels, -DRT_LARGE_NODES=64)
         self.L.har_set_link_mode(64 if quant_nodes else -1 if packed_links else 0)
         self.L.har_set_sphere_lights(1 if self.sphere_lights else 0)
         rc = self.L.har_render_frames_lanes(_p(u), _p(self.spheres), len(self.spheres), _p(self.tris), len(self.tris),

@@ -373,6 +373,8 @@ def test_python_renderer_mirror(scenes, tmp_path):
     r.render()
     orc.render_frames(3)
     assert np.array_equal(r.read_accum(), orc.accum_rgb())
+    image, at = r.present(wait=True)         # the canvas image of src/accumulator.ts:119-136
+    assert at == 3 and np.array_equal(image[:, :, :3], np.floor(orc.accum_rgb().astype(np.float64) * 255 + 0.5).astype(np.uint8))
     r.close()
     r.render()                               # no resources: silent no-op (src/webgpu-renderer.ts:238-246)
 
@@ -400,6 +402,27 @@ def test_five_thousand_single_frames(scenes):
         u[12] = f
         ctx.set_uniforms(u)
         ctx.render_frame()
+    assert np.array_equal(ctx.read_primary_ids(), orc.ids)
+    assert _f16_equal(ctx.read_frame_f16(), orc.frame_f16)
+    assert np.array_equal(ctx.read_accum(), orc.accum_rgb())
+    assert int(ctx.read_counters()[0]) == int(orc.counters[0])
+    ctx.close()
+
+
+@pytest.mark.parametrize("spp", [17, 4096, 4097])
+def test_sample_counts_beyond_the_ui_clamp(scenes, spp):
+    """The reference's UI clamps samples per pixel to 1..16 (src/webgpu-renderer.ts:219-221) but the shader loops
+    over whatever the uniform says (raytracer_compute.wgsl:299).  Through the C ABI any count is accepted: a lane of
+    the persistent kernel counts up to 4096 samples, a frame asking for more is rendered one thread per pixel."""
+    scene = scenes["boxes"]
+    width, height = 24, 10
+    orc = O.OracleRenderer(scene, width, height)
+    orc.samples_per_pixel = spp  # past set_samples_per_pixel's clamp
+    orc.render_frames(2)
+    ctx = capi.Context(width, height)
+    ctx.set_scene(S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles))
+    ctx.set_uniforms(S.pack_uniforms(scene.camera, 1, width, height, spp))
+    ctx.render_frames(1, 2)
     assert np.array_equal(ctx.read_primary_ids(), orc.ids)
     assert _f16_equal(ctx.read_frame_f16(), orc.frame_f16)
     assert np.array_equal(ctx.read_accum(), orc.accum_rgb())
