@@ -125,9 +125,10 @@ __host__ __device__ inline int stripe_global_row(const StripeMap &m, int local)
 #define RT_PARK2_MINW 6
 #endif
 
-template <int BLOCK, class Entry, int CAP = 1 << 30, bool SPILL = false, bool QUANT = false>
+template <int BLOCK, class Entry, int CAP = 1 << 30, bool SPILL = false, bool QUANT = false, bool SPHERES = true>
 struct LdsStack {
     static constexpr bool kQuantNodes = QUANT; // the links on this stack count 64-byte nodes (rt::lane_visit4q)
+    static constexpr bool kSphereLeaves = SPHERES; // leaves may hold spheres (rt::lane_step_triangle)
     Entry *base;
     int sp;
     // SPILL: entries CAP and above live in global memory, entry j of a lane at spill[(j - CAP) * spill_stride]
@@ -170,10 +171,14 @@ struct LdsStack {
 //          boxes; the same with 24-bit links for large scenes measured no gain).  Follows LINK16.
 //          64: the lanes visit the 64-byte nodes (8-bit child boxes relative to the node's own; large scenes).
 //   SL     the sphere-light extension (rt::lane_shade_closest<true>): seven more parked dwords per lane, in LDS
-template <int STACK_, int PARK_, int MINW_, bool LINK16_, bool SPILL_, int PLANE_LINKS_ = (LINK16_ && RT_PACKED_LINKS) ? 16 : 0, bool SL_ = false>
+//   SPHERES  leaves of the tree may hold spheres (scenes of many spheres).  A variant of its own: the sphere test inside
+//          the triangle step costs scenes without such leaves a quarter of their speed (131k-triangle height field
+//          15.9 -> 21.1 ms/frame, 991k triangles 12.5 -> 16.4) through the registers it takes.
+template <int STACK_, int PARK_, int MINW_, bool LINK16_, bool SPILL_, int PLANE_LINKS_ = (LINK16_ && RT_PACKED_LINKS) ? 16 : 0, bool SL_ = false,
+          bool SPHERES_ = false>
 struct LaneCfg {
     static constexpr int STACK = STACK_, PARK = PARK_, MINW = MINW_, PLANE_LINKS = PLANE_LINKS_;
-    static constexpr bool LINK16 = LINK16_, SPILL = SPILL_, SL = SL_;
+    static constexpr bool LINK16 = LINK16_, SPILL = SPILL_, SL = SL_, SPHERES = SPHERES_;
     static constexpr int PARK_LDS = PARK_ + (SL_ ? rt::kParkSecondShadowFloats : 0); // floats per lane in LDS
 };
 constexpr int kSpillEntries = 64 - RT_LARGE_STACK; // trees whose traversal needs up to 64 entries
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(kBlock, CFG::MINW) void render_persistent_kernel(rt
     __shared__ StackEntry lds_stack[STACK * kBlock];
     __shared__ float lds_park[CFG::PARK_LDS > 0 ? CFG::PARK_LDS * kBlock : 1];
     const int lane = threadIdx.x & 63;
-    LdsStack<kBlock, StackEntry, STACK, CFG::SPILL, CFG::PLANE_LINKS == 64> stack;
+    LdsStack<kBlock, StackEntry, STACK, CFG::SPILL, CFG::PLANE_LINKS == 64, CFG::SPHERES> stack;
     stack.base = lds_stack + threadIdx.x;
     stack.sp = 0;
     stack.spill = CFG::SPILL ? spill + ((size_t)blockIdx.x * kBlock + threadIdx.x) : nullptr;
@@ -1090,6 +1095,8 @@ int ensure_tile_order(rt_context *c, int which)
             RT_HIP_CHECK(hipMemset(c->d_tile_cost[which][k], 0, tiles * sizeof(unsigned int)));
         }
     if (!c->d_tile_order[which]) RT_HIP_CHECK(hipMalloc((void **)&c->d_tile_order[which], tiles * sizeof(uint32_t)));
+    // the zeroing above ran on the null stream, which the context's non-blocking streams do not wait for
+    RT_HIP_CHECK(hipStreamSynchronize(nullptr));
     RT_HIP_CHECK(hipMalloc((void **)&c->d_tile_cls[which], tiles * sizeof(uint32_t)));
     return RT_OK;
 }
@@ -1100,6 +1107,8 @@ int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchPar
     auto kernel = render_persistent_kernel<CFG, COUNT, FUSED>;
     if (CFG::PLANE_LINKS == 16 && c->host_scene.links_packed != CFG::PLANE_LINKS)
         return fail(RT_ERR_UNSUPPORTED, "internal: kernel variant and node link packing do not match");
+    if (!CFG::SPHERES && c->host_scene.n_tree_spheres != 0)
+        return fail(RT_ERR_UNSUPPORTED, "internal: kernel variant without the sphere test for a scene whose tree holds spheres");
     int per_cu = c->tune_blocks_per_cu;
     if (per_cu <= 0) {
         RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
@@ -1177,9 +1186,12 @@ using CfgSmallDeep = LaneCfg<32, 14, RT_MINW, true, false>;
 #endif
 using CfgLarge = LaneCfg<RT_LARGE_STACK, RT_LARGE_SLOTS, RT_LARGE_MINW, false, false, RT_LARGE_NODES>;
 using CfgLargeDeep = LaneCfg<RT_LARGE_STACK, RT_LARGE_SLOTS, RT_LARGE_MINW, false, true, RT_LARGE_NODES>;
-using CfgRegisters = LaneCfg<64, 0, 2, false, false>; // 64 KB of LDS per block: two blocks per CU
+using CfgRegisters = LaneCfg<64, 0, 2, false, false, 0, false, true>; // 64 KB of LDS per block: two blocks per CU
 // the sphere-light extension on small scenes: 22 x 2 + (14 + 7) x 4 = 128 bytes per lane, five blocks per CU
-using CfgSmallSL = LaneCfg<RT_PARK2_STACK, 14, 5, true, false, RT_PACKED_LINKS ? 16 : 0, true>;
+using CfgSmallSL = LaneCfg<RT_PARK2_STACK, 14, 5, true, false, RT_PACKED_LINKS ? 16 : 0, true, true>;
+// scenes of many spheres, whose spheres are leaves of the tree: CfgSmallDeep and CfgLargeDeep with the sphere test in
+using CfgSmallSpheres = LaneCfg<32, 14, RT_MINW, true, false, RT_PACKED_LINKS ? 16 : 0, false, true>;
+using CfgLargeSpheres = LaneCfg<RT_LARGE_STACK, RT_LARGE_SLOTS, RT_LARGE_MINW, false, true, RT_LARGE_NODES, false, true>;
 
 // Scenes whose links fit 16 bits: node indices below 32768 and leaf codes (first << 3 | count - 1) below 32768.
 bool scene_is_small(const rt_context *c)
@@ -1200,8 +1212,8 @@ bool sphere_lights_on_persistent(const rt_context *c)
 // its traversal stack in global memory.
 bool scene_spills(const rt_context *c)
 {
-    return rt::kWideBvh && c->tune_lds_state != 0 && !scene_is_small(c) && persistent_stack_need(c) > (uint32_t)CfgLarge::STACK &&
-           persistent_stack_need(c) <= kMaxStackEntries;
+    return rt::kWideBvh && c->tune_lds_state != 0 && !scene_is_small(c) && persistent_stack_need(c) <= kMaxStackEntries &&
+           (persistent_stack_need(c) > (uint32_t)CfgLarge::STACK || c->host_scene.n_tree_spheres != 0);
 }
 
 // Makes the stack overflow area of stream `which` (0 main, 1.. side streams) hold a column per lane of `blocks` blocks.
@@ -1226,12 +1238,17 @@ int spill_blocks_max(rt_context *c, uint64_t &blocks)
 {
     int most = c->tune_blocks_per_cu;
     if (most <= 0) {
-        int n[4] = {0, 0, 0, 0};
+        int n[8] = {};
         RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[0], render_persistent_kernel<CfgLargeDeep, false, false>, kBlock, 0));
         RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[1], render_persistent_kernel<CfgLargeDeep, false, true>, kBlock, 0));
         RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[2], render_persistent_kernel<CfgLargeDeep, true, false>, kBlock, 0));
         RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[3], render_persistent_kernel<CfgLargeDeep, true, true>, kBlock, 0));
-        most = std::max(1, std::max(std::max(n[0], n[1]), std::max(n[2], n[3])));
+        RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[4], render_persistent_kernel<CfgLargeSpheres, false, false>, kBlock, 0));
+        RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[5], render_persistent_kernel<CfgLargeSpheres, false, true>, kBlock, 0));
+        RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[6], render_persistent_kernel<CfgLargeSpheres, true, false>, kBlock, 0));
+        RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[7], render_persistent_kernel<CfgLargeSpheres, true, true>, kBlock, 0));
+        most = 1;
+        for (int v : n) most = std::max(most, v);
     }
     blocks = (uint64_t)c->n_cus * most;
     return RT_OK;
@@ -1249,10 +1266,13 @@ int launch_persistent_d(rt_context *c, const rt::FrameParams &fp, const BatchPar
         if (!sphere_lights_on_persistent(c)) return fail(RT_ERR_UNSUPPORTED, "internal: sphere lights on a scene the persistent kernel does not take");
         return launch_persistent_t<CfgSmallSL, COUNT, FUSED>(c, fp, bp, counter, stream);
     }
+    const bool tree_spheres = c->host_scene.n_tree_spheres != 0; // leaves of spheres: the variants with the sphere test in the triangle step
     if (small) {
+        if (tree_spheres) return launch_persistent_t<CfgSmallSpheres, COUNT, FUSED>(c, fp, bp, counter, stream);
         if (depth <= (uint32_t)CfgSmall::STACK && c->tune_lds_state >= 2) return launch_persistent_t<CfgSmall, COUNT, FUSED>(c, fp, bp, counter, stream);
         return launch_persistent_t<CfgSmallDeep, COUNT, FUSED>(c, fp, bp, counter, stream);
     }
+    if (tree_spheres) return launch_persistent_t<CfgLargeSpheres, COUNT, FUSED>(c, fp, bp, counter, stream);
     if (depth <= (uint32_t)CfgLarge::STACK) return launch_persistent_t<CfgLarge, COUNT, FUSED>(c, fp, bp, counter, stream);
     return launch_persistent_t<CfgLargeDeep, COUNT, FUSED>(c, fp, bp, counter, stream);
 }
@@ -1915,13 +1935,14 @@ int rt_present(rt_context *c, uint8_t *rgba8, int wait, uint32_t *frame_index)
     if (wait) RT_FLUSH_PENDING(c);
     RT_HIP_CHECK(hipSetDevice(c->device));
     const size_t px = (size_t)c->width * c->height;
-    if (!c->copy_stream) {
-        RT_HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->present_done[1]) {
+        // made on first use; a call that failed half way is completed by the next one (present_done[1] is made last)
+        if (!c->copy_stream) RT_HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         for (int k = 0; k < 2; k++) {
-            RT_HIP_CHECK(hipMalloc((void **)&c->d_present[k], px * 4));
-            RT_HIP_CHECK(hipHostMalloc((void **)&c->h_present[k], px * 4, hipHostMallocDefault));
-            RT_HIP_CHECK(hipEventCreateWithFlags(&c->present_ready[k], hipEventDisableTiming));
-            RT_HIP_CHECK(hipEventCreateWithFlags(&c->present_done[k], hipEventDisableTiming));
+            if (!c->d_present[k]) RT_HIP_CHECK(hipMalloc((void **)&c->d_present[k], px * 4));
+            if (!c->h_present[k]) RT_HIP_CHECK(hipHostMalloc((void **)&c->h_present[k], px * 4, hipHostMallocDefault));
+            if (!c->present_ready[k]) RT_HIP_CHECK(hipEventCreateWithFlags(&c->present_ready[k], hipEventDisableTiming));
+            if (!c->present_done[k]) RT_HIP_CHECK(hipEventCreateWithFlags(&c->present_done[k], hipEventDisableTiming));
         }
     }
     // newest image asked for so far
@@ -1940,7 +1961,7 @@ int rt_present(rt_context *c, uint8_t *rgba8, int wait, uint32_t *frame_index)
         RT_HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->present_ready[k], 0));
         RT_HIP_CHECK(hipMemcpyAsync(c->h_present[k], c->d_present[k], px * 4, hipMemcpyDeviceToHost, c->copy_stream));
         RT_HIP_CHECK(hipEventRecord(c->present_done[k], c->copy_stream));
-        // the next convert into this slot must not overtake the copy: the context's stream waits for it when the slot comes round
+        // (the next convert into this slot cannot overtake this copy: the host waits for present_done[k] above first)
         c->present_used[k] = true;
         c->present_serial[k] = c->launch_serial;
         c->present_frame[k] = c->launched_frame;

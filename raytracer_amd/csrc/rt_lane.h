@@ -152,13 +152,19 @@ template <class T>
 struct stack_quant_nodes<T, std::void_t<decltype(T::kQuantNodes)>> : std::integral_constant<bool, T::kQuantNodes> {};
 
 // Address of the record a link points at: a 4-wide node (128- or 64-byte form) or the first triangle of a leaf.
-template <bool QUANT>
+// Whether a stack type says that leaves may hold spheres (Stack::kSphereLeaves; yes unless it says otherwise).
+template <class T, class = void>
+struct stack_sphere_leaves : std::true_type {};
+template <class T>
+struct stack_sphere_leaves<T, std::void_t<decltype(T::kSphereLeaves)>> : std::integral_constant<bool, T::kSphereLeaves> {};
+
+template <bool QUANT, bool SPHERES = true>
 RT_HD const char *link_address(const SceneView &sc, int32_t link)
 {
     if (link < 0) {
         uint32_t first = (uint32_t)~link >> 3;
-        return leaf_holds_spheres(sc, first) ? (const char *)(sc.sph_leaf + (first - sc.n_tris))
-                                             : (const char *)(sc.tri_isect + kTriRecord * (size_t)first);
+        return SPHERES && leaf_holds_spheres(sc, first) ? (const char *)(sc.sph_leaf + (first - sc.n_tris))
+                                                        : (const char *)(sc.tri_isect + kTriRecord * (size_t)first);
     }
     return QUANT ? (const char *)sc.nodes4q + ((size_t)link << 6) : (const char *)sc.nodes4 + ((size_t)link << 7);
 }
@@ -421,7 +427,7 @@ RT_HD void lane_step_triangle(const SceneView &sc, Lane &L, Stack &stack, TestCo
 {
     uint32_t code = (uint32_t)~L.cur;
     uint32_t first = code >> 3, left = code & 7u; // triangles after this one
-    if (leaf_holds_spheres(sc, first)) {
+    if (stack_sphere_leaves<Stack>::value && leaf_holds_spheres(sc, first)) {
         // a sphere of a leaf of spheres: the sphere part of ray_all (raytracer_compute.wgsl:19-24) for this one,
         // as lane_test_spheres does it for spheres outside the tree; ids are original indices, all below any
         // triangle's, so on a tie in t the lower number wins whatever the other is
@@ -449,7 +455,7 @@ RT_HD void lane_step_triangle(const SceneView &sc, Lane &L, Stack &stack, TestCo
     float touched = 0.0f;
     if constexpr (stack_touches_top<Stack>::value) {
         // what the lane visits after this leaf is known already: start bringing it into the caches
-        if (left == 0u && stack.top_in_lds()) touched = *(const float *)link_address<stack_quant_nodes<Stack>::value>(sc, stack.top());
+        if (left == 0u && stack.top_in_lds()) touched = *(const float *)link_address<stack_quant_nodes<Stack>::value, stack_sphere_leaves<Stack>::value>(sc, stack.top());
     }
     float t = triangle_t(L.o, L.d, xyz(a), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x));
     if (cnt) cnt->tris++;
