@@ -825,11 +825,7 @@ __global__ void finish_sums_kernel(float *planes, size_t n, float divisor)
 // cls: scratch of one entry per tile; order: out, a permutation of each queue's tiles, most expensive
 // of 256 cost classes first.  Every tile's cost is read exactly once, so the result is a permutation
 // whatever the values are; the order within a class is whatever the atomic counters make it, which no result
-// depends on.  Measured alternatives: 32 classes with image order inside them (a stable scatter) lose a quarter
-// on the large scenes (991k triangles 11.9 -> 15.6 ms/frame, the 131k-triangle height field 15.9 -> 21.0, as slow
-// as a launch without any cost information), nothing on the small ones; spreading neighbouring tiles apart in a
-// launch that has no costs yet (a stride permutation) changes nothing: it is the resolution of the cost order
-// that counts, not where the tiles in hand at one moment lie.
+// depends on.
 __global__ __launch_bounds__(256) void order_tiles_kernel(const unsigned int *cost, uint32_t *cls, uint32_t *order, uint32_t tiles_per_frame)
 {
     __shared__ unsigned int top, bins[256];
