@@ -178,9 +178,13 @@ RT_HD void lane_pop(Lane &L, Stack &stack)
 
 // Sphere part of ray_all (raytracer_compute.wgsl:19-24) for the lane's ray,
 // merged into L.tmax / L.best_id under the reference's selection rule.
+// TREE_SPHERES: the scene may keep spheres in the tree, the rest (n_linear_spheres) are tested here; without it
+// all n_spheres are, and the kernel needs one value less.
+template <bool TREE_SPHERES>
 RT_HD void lane_test_spheres(const SceneView &sc, Lane &L, TestCounts *cnt)
 {
-    for (uint32_t i = 0; i < sc.n_linear_spheres; i++) {
+    const uint32_t n_linear = TREE_SPHERES ? sc.n_linear_spheres : sc.n_spheres;
+    for (uint32_t i = 0; i < n_linear; i++) {
         f4 s0 = read_uniform(sc.spheres + 4 * i);
         float tn;
         float t = sphere_t(L.o, L.d, s0, tn);
@@ -211,19 +215,21 @@ RT_HD void lane_launch_ray(const SceneView &sc, Lane &L, Stack &stack, bool anyh
     if (all_nan(L.d)) L.cur = kNoRoot; // every test of the reference fails on a NaN direction
     else {
         L.rb = make_raybox(L.o, L.d);
-        lane_test_spheres(sc, L, cnt);
+        lane_test_spheres<stack_sphere_leaves<Stack>::value>(sc, L, cnt);
     }
     if (L.cur == kNoRoot) L.mode = anyhit ? kLaneShadowDone : kLaneShadeClosest;
 }
 
 // The sphere part of a closest-hit ray_all for a ray that is launched later (the bounce ray set
 // aside behind a shadow ray): best t and id over the spheres, (INFINITY, kNoHit) if none.
+template <bool TREE_SPHERES>
 RT_HD void spheres_closest(const SceneView &sc, f3 o, f3 d, float &best_t, int32_t &best_id, TestCounts *cnt)
 {
     best_t = INFINITY;
     best_id = kNoHit;
     if (all_nan(d)) return;
-    for (uint32_t i = 0; i < sc.n_linear_spheres; i++) {
+    const uint32_t n_linear = TREE_SPHERES ? sc.n_linear_spheres : sc.n_spheres;
+    for (uint32_t i = 0; i < n_linear; i++) {
         float tn;
         float t = sphere_t(o, d, read_uniform(sc.spheres + 4 * i), tn);
         if (cnt) cnt->spheres++;
@@ -616,7 +622,7 @@ RT_HD void lane_shade_closest(const SceneView &sc, const FrameParams &fp, Lane &
             if (cont) {
                 float nt;
                 int32_t nid;
-                spheres_closest(sc, no, nd, nt, nid, cnt);
+                spheres_closest<stack_sphere_leaves<Stack>::value>(sc, no, nd, nt, nid, cnt);
                 park.put(kParkNextT, nt);
                 park.put(kParkNextId, u2f((uint32_t)nid));
             }

@@ -20,7 +20,9 @@ def insts(a, b): return sum(1 for l in body[a:b] if re.match(r"^\s+[vsgdb]\w*_\w
 print("kernel lines", len(body), "instructions", insts(0, len(body)), "loops", len(loops))
 for a, b in sorted(loops, key=lambda t: t[1] - t[0]):
     n = sum(1 for l in body[a:b] if "scratch_" in l)
-    print("loop lines %d-%d: %d instructions, %d scratch accesses, %d global/ds loads" % (a, b, insts(a, b), n, sum(1 for l in body[a:b] if re.search(r"global_load|ds_read", l))))
+    lanes = sum(1 for l in body[a:b] if re.search(r"v_readlane_b32|v_writelane_b32", l))
+    print("loop lines %d-%d: %d instructions, %d scratch accesses, %d global/ds loads, %d v_readlane/v_writelane (scalar spills)"
+          % (a, b, insts(a, b), n, sum(1 for l in body[a:b] if re.search(r"global_load|ds_read", l)), lanes))
 tot = [i for i, l in enumerate(body) if "scratch_" in l]
 print("scratch accesses in the kernel:", len(tot))
 for i in tot:
