@@ -12,7 +12,8 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+# RT_HIP_LIBRARY names another build of the library (A/B runs of compiler options); the default is the in-tree one
+LIB_PATH = os.environ.get("RT_HIP_LIBRARY") or os.path.join(_HERE, "librt_hip.so")
 
 RT_MODE_BVH = 0
 RT_MODE_BRUTE_FORCE = 1
