@@ -210,6 +210,10 @@ int rt_render_frames(rt_context *ctx, uint32_t first_frame_index, uint32_t n_fra
  * contexts of one GPU must not overlap in time (finish one with rt_sync before starting another),
  * or they race on the array.  The array keeps the previous call's contents; the counter is
  * cleared at the start of every launch and the colours are written before they are read.
+ * What the library cannot speak for: the HIP runtime loads a kernel's code and reserves the scratch
+ * memory of its register spills (16 MiB on an MI355X) the first time a process launches that kernel.
+ * A caller that must see no allocation at all, the runtime's included, renders one frame of a scene
+ * of the same kind with rt_render_frames first.
  */
 int rt_render_frames_noalloc(rt_context *ctx, uint32_t first_frame_index, uint32_t n_frames);
 

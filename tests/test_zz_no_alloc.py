@@ -89,6 +89,16 @@ def test_noalloc_on_a_scene_whose_stack_overflows_into_global_memory():
     scene = card_deck_scene(3000)
     spheres, tris = S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles)
     width, height, spp = 64, 36, 2
+    # The HIP runtime loads a kernel's code and reserves the scratch memory of its register spills the first time a
+    # process launches it (16 MiB here).  That is not the library's doing and not what this test is about: another
+    # context launches the same kernels first, so that the runtime has done it when the free memory is read.
+    other = capi.Context(width, height)
+    other.set_scene(spheres, tris)
+    other.set_uniforms(S.pack_uniforms(scene.camera, 1, width, height, spp))
+    other.render_frames(1, 2)
+    other.render_frame()
+    other.sync()
+    other.close()
     for warm_up in (False, True):
         ctx = capi.Context(width, height)
         ctx.set_scene(spheres, tris)
@@ -128,3 +138,33 @@ def test_noalloc_limits(scenes):
     _same(ctx, ref)
     ctx.close()
     ref.close()
+
+
+def test_contexts_give_back_what_they_allocated(scenes):
+    """Contexts that used every lazily made buffer (batch buffer, side streams and staging slots, tile-order tables,
+    the presented image's device and pinned buffers, row staging, stack overflow area) leave device memory as they
+    found it when closed: the free memory after twenty such contexts equals the free memory after the first."""
+    import torch
+    from tests.synth import heightfield_scene
+
+    small, deep = scenes["suzanne"], heightfield_scene(48)
+
+    def use_a_context():
+        for scene in (small, deep):
+            ctx = capi.Context(128, 72)
+            ctx.set_scene(S.pack_spheres(scene.spheres), S.pack_triangles(scene.triangles))
+            ctx.set_uniforms(S.pack_uniforms(scene.camera, 1, 128, 72, 4))
+            ctx.render_frame()
+            ctx.render_frames(2, 3)
+            ctx.present(wait=True)
+            ctx.read_accum()
+            ctx.close()
+
+    use_a_context()
+    torch.cuda.synchronize()
+    free_after_first = torch.cuda.mem_get_info()[0]
+    for _ in range(20):
+        use_a_context()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_after_first
+
