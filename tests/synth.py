@@ -1,5 +1,6 @@
 """Deterministic synthetic scenes for tests: a height-field mesh inside the
-reference's box room (no random numbers)."""
+reference's box room and other constructed scenes (no random numbers), and
+seeded random scenes (random_scene)."""
 import math
 
 import numpy as np
@@ -132,3 +133,52 @@ def sphere_field_scene(n: int, with_triangles: bool = True) -> S.Scene:
         spheres[5]["center"] = [0.0, 2.5, 4.0]   # one unit in front of the camera (scene_boxes: position 0, 2.5, 5)
         spheres[5]["radius"] = 0.995
     return S.Scene(camera=boxes.camera, spheres=spheres, triangles=boxes.triangles if with_triangles else [])
+
+
+
+def random_scene(seed: int, n_tris: int = -1) -> S.Scene:
+    """A seeded random scene: 0..14 spheres and 0..400 triangles of random size, place and material inside a
+    6 x 4 x 6 volume in front of a randomly placed and rotated camera; about one primitive in eight emits, one in
+    five is a mirror or partly one; clusters of small triangles next to wall-sized ones, a few exact duplicates,
+    and now and then a primitive around or behind the camera.  n_tris overrides the random triangle count (the kernels
+    for scenes of more than 4096 triangles).  Same seed and count, same scene."""
+    import random
+
+    rng = random.Random(seed)
+
+    def material():
+        emits = rng.random() < 0.125
+        shiny = rng.random() < 0.2
+        return dict(color=[rng.random(), rng.random(), rng.random()],
+                    emissionColor=[rng.random(), rng.random(), rng.random()] if emits else [0.0, 0.0, 0.0],
+                    emissionStrength=rng.uniform(0.5, 6.0) if emits else 0.0,
+                    smoothness=rng.random() if shiny else 0.0,
+                    specularProbability=rng.choice([1.0, rng.random()]) if shiny else 0.0)
+
+    def point(spread=1.0):
+        return [rng.uniform(-3.0, 3.0) * spread, rng.uniform(0.0, 4.0) * spread, rng.uniform(-6.0, 0.0) * spread]
+
+    spheres = []
+    for _ in range(rng.choice([0, 1, 2, 3, 8, 9, 14])):
+        c = point()
+        spheres.append(dict(center=c, radius=rng.choice([0.05, 0.3, 0.8, 2.5]) * rng.uniform(0.5, 1.5), **material()))
+    triangles = []
+    drawn = rng.choice([0, 1, 7, 40, 150, 400])
+    n_tris = drawn if n_tris < 0 else n_tris
+    while len(triangles) < n_tris:
+        size = rng.choice([0.02, 0.2, 1.0, 5.0])
+        a = point()
+        b = [a[k] + rng.uniform(-size, size) for k in range(3)]
+        c = [a[k] + rng.uniform(-size, size) for k in range(3)]
+        m = material()
+        triangles.append(dict(v0=a, v1=b, v2=c, **m))
+        if rng.random() < 0.5:                      # the same triangle facing the other way
+            triangles.append(dict(v0=a, v1=c, v2=b, **m))
+        if rng.random() < 0.03:                     # an exact duplicate: the first must win the tie
+            triangles.append(dict(triangles[-1]))
+    if spheres and rng.random() < 0.3:              # a sphere around the camera
+        spheres[0]["center"], spheres[0]["radius"] = [0.2, 2.0, 3.1], 1.5
+    camera = dict(position=[rng.uniform(-1.0, 1.0), rng.uniform(1.0, 3.0), rng.uniform(2.0, 4.0)],
+                  rotation=[rng.uniform(-20.0, 10.0), rng.uniform(-25.0, 25.0), 0.0],
+                  fov=rng.uniform(30.0, 90.0), nearPlane=0.1, farPlane=100.0)
+    return S.Scene(camera=camera, spheres=spheres, triangles=triangles)

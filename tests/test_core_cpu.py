@@ -277,3 +277,23 @@ def test_sphere_light_extension_matches_oracle(brute):
     on.set_samples_per_pixel(3)
     on.render()
     assert not np.array_equal(on.accum, off.accum) and int(on.counters[0]) > int(off.counters[0])
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_scenes_match_oracle(seed):
+    """Seeded random scenes (tests.synth.random_scene): the traversal of the shared core and the lane state
+    machine against the oracle's brute-force scan."""
+    from tests.synth import random_scene
+
+    scene = random_scene(seed)
+    compare(scene, 40, 23, 1, 2, False)
+    orc = O.OracleRenderer(scene, 40, 23)
+    orc.set_samples_per_pixel(2)
+    orc.render_frames(2)
+    har = HarnessRenderer(scene, 40, 23)
+    har.render_frames_lanes(2, 1, 2)
+    assert np.array_equal(har.ids, orc.ids)
+    assert np.array_equal(har.frame_f16, orc.frame_f16)
+    assert np.array_equal(har.accum, orc.accum)
+    assert int(har.counters[0]) == int(orc.counters[0])
+

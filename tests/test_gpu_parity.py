@@ -641,3 +641,27 @@ def test_presented_image(scenes):
     assert at == frames + 2
     assert np.array_equal(img[:, :, :3], np.floor(orc.accum_rgb().astype(np.float64) * 255 + 0.5).astype(np.uint8))
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_scenes_bit_exact(seed):
+    """Seeded random scenes (tests.synth.random_scene: random primitives, materials, lights and camera): the
+    persistent kernel frame by frame, the one-thread-per-pixel kernel, and a batch, against the oracle."""
+    from tests.synth import random_scene
+
+    scene = random_scene(seed)
+    run_pair(scene, 48, 27, 2, 3, capi.RT_MODE_BVH)
+    run_pair(scene, 48, 27, 1, 2, capi.RT_MODE_BVH_TILES)
+    run_batched(scene, 48, 27, 3, 4, 2)
+
+
+@pytest.mark.parametrize("seed,n_tris", [(1000, 4500), (1001, 9000), (1002, 20000)])
+def test_random_large_scenes_bit_exact(seed, n_tris):
+    """The same with thousands of random triangles: the kernels for scenes of more than 4096 triangles (32-bit
+    links, stack overflow area in global memory, a leaf's triangles in one step)."""
+    from tests.synth import random_scene
+
+    scene = random_scene(seed, n_tris)
+    run_pair(scene, 32, 18, 2, 2, capi.RT_MODE_BVH)
+    run_batched(scene, 32, 18, 3, 2, 2)
+
