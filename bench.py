@@ -46,7 +46,8 @@ import numpy as np  # noqa: E402
 
 SPP = 16
 PEAK_FP32_TFLOPS = 157.3  # MI355X FP32 vector peak (packed FMA), chip-level spec
-# algorithmic flop prices per test / per bounce ("Roofline accounting")
+# algorithmic flop prices: one 4-wide node visit (four slab tests: 24 FMAs), one Moeller-Trumbore test, one sphere
+# test, one bounce (light sample, BRDF, MIS weights, next direction), counted as the shader's own arithmetic
 F_BOX, F_TRI, F_SPH, F_SHADE = 24, 52, 31, 160
 
 CONFIGS = {

@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from raytracer_amd import capi, scene as S
 name = sys.argv[1] if len(sys.argv) > 1 else "suzanne"
-W, H, spp, frames = 1920, 1080, 16, int(os.environ.get("PS_FRAMES", "16"))
+W, H, spp, frames = 1920, 1080, int(os.environ.get("PS_SPP", "16")), int(os.environ.get("PS_FRAMES", "16"))
 if name.startswith("hf"):      # hf256: height field of 256 x 256 quads
     from tests.synth import heightfield_scene
     sc = heightfield_scene(int(name[2:]))
