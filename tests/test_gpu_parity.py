@@ -665,3 +665,19 @@ def test_random_large_scenes_bit_exact(seed, n_tris):
     run_pair(scene, 32, 18, 2, 2, capi.RT_MODE_BVH)
     run_batched(scene, 32, 18, 3, 2, 2)
 
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_call_sequences(seed):
+    """Random sequences of calls on one context (tests/harness/fuzz_sequences.py): unfenced single-frame submissions,
+    batches, the entry point that allocates nothing, moving cameras, changing sample counts, frame-index jumps, reads
+    and presents in between, with the oracle driven the same way."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "harness", "fuzz_sequences.py")
+    spec = importlib.util.spec_from_file_location("fuzz_sequences", path)
+    module = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(module)
+    ok, size, log = module.run_sequence(seed)
+    assert ok, "sequence %d differs: %s %s" % (seed, size, log)
+
