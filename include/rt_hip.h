@@ -48,8 +48,9 @@ typedef enum rt_mode {
 
 /* Scheduling knobs of the persistent kernel (rt_set_tuning); none changes the output. */
 typedef enum rt_tuning {
-    RT_TUNE_SHADE_NUM = 0,     /* shade finished lanes when traversing lanes * 8 < active lanes * value (0..8) */
-    RT_TUNE_LEAF_LANES = 1,    /* visit leaves once this many lanes of a wave wait at one (1..64)               */
+    RT_TUNE_SHADE_NUM = 0,     /* shade finished lanes when traversing lanes * 8 < active lanes * value (0..8);
+                                  default 2, 3 for scenes of more than 4096 triangles */
+    RT_TUNE_LEAF_LANES = 1,    /* visit leaves once this many lanes of a wave wait at one (1..64); default 12, 16 for such scenes */
     RT_TUNE_BLOCKS_PER_CU = 2, /* resident 256-thread blocks per CU; 0 = occupancy query                        */
     RT_TUNE_BATCH_FRAMES = 3,  /* frames traced per launch by rt_render_frames; 0 = automatic (default)        */
     RT_TUNE_SHADOW_DONE_LANES = 4, /* finish shadow rays once this many lanes of a wave wait for it (1..64)     */
