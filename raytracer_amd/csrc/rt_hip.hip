@@ -1148,7 +1148,7 @@ int launch_persistent_t(rt_context *c, const rt::FrameParams &fp, const BatchPar
     // Starting a pixel (seed, jitter, camera ray) is long code: with few samples per pixel it runs
     // often, so more idle lanes are collected before a refill (measured optimum per spp).
     int refill = c->tune_refill_lanes;
-    if (refill <= 0) refill = fp.spp <= 1u ? 32 : fp.spp <= 2u ? 24 : fp.spp <= 4u ? 16 : fp.spp <= 8u ? 8 : 4;
+    if (refill <= 0) refill = fp.spp <= 2u ? 16 : fp.spp <= 8u ? 8 : 4;
     // Scenes of many triangles shade a little earlier and collect more lanes before a triangle step (each measured on
     // the 131k-triangle height field and on 991k triangles unseen / seen: 15.9 / 10.3 / 12.4 -> 15.2 / 9.7 / 12.3 ms/frame;
     // the small scenes lose 3 % with these values and keep theirs).
